@@ -1,0 +1,468 @@
+"""CPU oracle for the convolutional-autoencoder compress/decompress hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``cnn_autoencoder_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg use it, and only as the checker.
+
+What is restated here, and what pins it:
+
+* Analysis / synthesis conv stacks (reference ``src/models/tasks/_autoencoders.py``
+  :53-101 DownsamplingUnit, :177-227 UpsamplingUnit, :307-361 Analyzer, :364-455
+  Synthesizer) -- restated with ``torch.nn.functional`` on CPU and PINNED against
+  golden tensors emitted by the reference's own classes (``oracle/gen_golden.py``,
+  fixtures under ``tests/golden/``).
+* GDN / IGDN, the factorized EntropyBottleneck (likelihood, CDF construction,
+  quantiser), ``pmf_to_quantized_cdf`` and the rANS coder live in the third-party
+  package ``compressai`` (``requirements.txt:25``: ``compressai>=1.2.4``, un-pinned,
+  not vendored, absent from this image).  They are restated from the published
+  algorithm and anchored on the reference call sites
+  ``_autoencoders.py:29-30`` (GDN), ``:476-477`` (EntropyBottleneck ctor), ``:502``
+  (update), ``:549-551`` (compress), ``:568-571`` (decompress).
+  **PARITY UNPINNED** for these: the reference holds no tests or vectors for them
+  and ``compressai`` cannot be executed here.  They are cross-checked by invariants,
+  hand-worked known-answer vectors (``tests/golden/rans_kat.json``) and by agreement
+  between three independent implementations (this file, ``oracle/rans64_oracle.c``
+  and the HIP/C++ product).
+"""
+from __future__ import annotations
+
+import math
+import struct
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# GDN (compressai.layers.GDN; reference call site _autoencoders.py:29-30)
+# --------------------------------------------------------------------------------------
+
+REPARAM_OFFSET = 2.0 ** -18
+PEDESTAL = REPARAM_OFFSET ** 2  # 2**-36
+
+
+def nonneg_init(x: torch.Tensor) -> torch.Tensor:
+    """NonNegativeParametrizer.init: sqrt(max(x + pedestal, pedestal))."""
+    ped = torch.tensor([PEDESTAL], dtype=x.dtype)
+    return torch.sqrt(torch.max(x + ped, ped))
+
+
+def nonneg_reparam(p: torch.Tensor, minimum: float) -> torch.Tensor:
+    """NonNegativeParametrizer.forward: max(p, bound)**2 - pedestal."""
+    bound = (minimum + PEDESTAL) ** 0.5
+    ped = torch.tensor([PEDESTAL], dtype=p.dtype)
+    out = torch.max(p, torch.tensor([bound], dtype=p.dtype))
+    return out ** 2 - ped
+
+
+def gdn_init_params(channels: int, gamma_init: float = 0.1) -> Tuple[torch.Tensor, torch.Tensor]:
+    beta = nonneg_init(torch.ones(channels))
+    gamma = nonneg_init(gamma_init * torch.eye(channels))
+    return beta, gamma
+
+
+def gdn_forward(x: torch.Tensor, beta: torch.Tensor, gamma: torch.Tensor,
+                inverse: bool = False, beta_min: float = 1e-6) -> torch.Tensor:
+    """x (B,C,H,W) fp32; beta (C), gamma (C,C) are the *stored* (pre-reparam) tensors."""
+    C = x.shape[1]
+    b = nonneg_reparam(beta, beta_min)
+    g = nonneg_reparam(gamma, 0.0).reshape(C, C, 1, 1)
+    norm = F.conv2d(x ** 2, g, b)
+    norm = torch.sqrt(norm) if inverse else torch.rsqrt(norm)
+    return x * norm
+
+
+# --------------------------------------------------------------------------------------
+# Conv stacks (reference-pinned)
+# --------------------------------------------------------------------------------------
+
+def reflect_conv_s2(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                    stride: int = 2) -> torch.Tensor:
+    """nn.Conv2d(k, stride, padding=k//2, padding_mode='reflect') -- _autoencoders.py:78-85."""
+    k = w.shape[-1]
+    p = k // 2
+    xp = F.pad(x, (p, p, p, p), mode='reflect') if p > 0 else x
+    return F.conv2d(xp, w, bias, stride=stride)
+
+
+def deconv_s2(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.ConvTranspose2d(k, stride 2, padding k//2, output_padding 1) -- _autoencoders.py:204-211."""
+    k = w.shape[-1]
+    return F.conv_transpose2d(x, w, bias, stride=2, padding=k // 2, output_padding=1)
+
+
+def analysis_forward(x: torch.Tensor, layers: Sequence[dict]) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """GDN-variant Analyzer: layers[i] = {'weight', 'bias'?, 'beta'?, 'gamma'?}.
+
+    Layer i = reflect conv s2 followed by GDN when 'beta' is present
+    (DownsamplingUnit with act_layer_type='GDN': model.0 = conv, model.1 = GDN;
+    last unit has act None, _autoencoders.py:343-351).
+    Returns (y, per-layer outputs).
+    """
+    outs = []
+    fx = x
+    for L in layers:
+        fx = reflect_conv_s2(fx, L['weight'], L.get('bias'))
+        if L.get('beta') is not None:
+            fx = gdn_forward(fx, L['beta'], L['gamma'], inverse=False)
+        outs.append(fx)
+    return fx, outs
+
+
+def synthesis_forward(y: torch.Tensor, layers: Sequence[dict]) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """GDN-variant Synthesizer (UpsamplingUnit: model.0 = convT, model.1 = IGDN)."""
+    outs = []
+    fx = y
+    for L in layers:
+        fx = deconv_s2(fx, L['weight'], L.get('bias'))
+        if L.get('beta') is not None:
+            fx = gdn_forward(fx, L['beta'], L['gamma'], inverse=True)
+        outs.append(fx)
+    return fx, outs
+
+
+def tile_to_input(tile_u8: np.ndarray) -> torch.Tensor:
+    """(h,w,c) uint8 -> (1,c,h,w) fp32 / 255  -- _autoencoders.py:542-545."""
+    t = torch.from_numpy(np.ascontiguousarray(tile_u8)).permute(2, 0, 1)
+    return (t.float() / 255.0).unsqueeze(0)
+
+
+def output_to_tile(x_r: torch.Tensor) -> np.ndarray:
+    """(c,h,w) fp32 -> (h,w,c) uint8: *255, clip, truncating cast -- _autoencoders.py:576-580."""
+    t = (x_r * 255.0).clip(0, 255).to(torch.uint8)
+    return np.ascontiguousarray(t.permute(1, 2, 0).numpy())
+
+
+# --------------------------------------------------------------------------------------
+# pmf_to_quantized_cdf (compressai._CXX, Appendix A.2)  -- pure python restatement
+# --------------------------------------------------------------------------------------
+
+def pmf_to_quantized_cdf(pmf: Sequence[float], precision: int = 16) -> List[int]:
+    pmf32 = np.asarray(pmf, dtype=np.float32)
+    if not np.all(np.isfinite(pmf32)) or np.any(pmf32 < 0):
+        raise ValueError("Invalid `pmf`, non-finite or negative element found")
+    scale = np.float32(1 << precision)
+    cdf = [0] * (len(pmf32) + 1)
+    for i, p in enumerate(pmf32):
+        v = np.float32(p) * scale
+        # std::round: half away from zero (values are >= 0)
+        cdf[i + 1] = int(math.floor(float(v) + 0.5))
+    total = sum(cdf) & 0xFFFFFFFF
+    if total == 0:
+        raise ValueError("Invalid `pmf`: at least one element must have a non-zero probability.")
+    cdf = [((1 << precision) * c) // total for c in cdf]
+    acc = 0
+    for i in range(len(cdf)):
+        acc += cdf[i]
+        cdf[i] = acc
+    cdf[-1] = 1 << precision
+    n = len(cdf)
+    for i in range(n - 1):
+        if cdf[i] == cdf[i + 1]:
+            best_freq = 0xFFFFFFFF
+            best_steal = -1
+            for j in range(n - 1):
+                freq = cdf[j + 1] - cdf[j]
+                if freq > 1 and freq < best_freq:
+                    best_freq = freq
+                    best_steal = j
+            assert best_steal != -1
+            if best_steal < i:
+                for j in range(best_steal + 1, i + 1):
+                    cdf[j] -= 1
+            else:
+                assert best_steal > i
+                for j in range(i + 1, best_steal + 1):
+                    cdf[j] += 1
+    assert cdf[0] == 0 and cdf[-1] == (1 << precision)
+    for i in range(n - 1):
+        assert cdf[i + 1] > cdf[i]
+    return cdf
+
+
+# --------------------------------------------------------------------------------------
+# rANS64 (compressai.ans / ryg_rans rans64.h, Appendix A.3) -- pure python restatement
+# (slow: small cases only; the C restatement in rans64_oracle.c is the fast checker)
+# --------------------------------------------------------------------------------------
+
+RANS64_L = 1 << 31
+PRECISION = 16
+BYPASS_PRECISION = 4
+MAX_BYPASS_VAL = (1 << BYPASS_PRECISION) - 1
+M64 = (1 << 64) - 1
+
+
+def rans_symbolize(symbols, indexes, cdfs, cdf_lengths, offsets):
+    """Per-symbol (start, range, bypass) stack exactly as BufferedRansEncoder builds it."""
+    syms = []
+    for s, idx in zip(symbols, indexes):
+        cdf = cdfs[idx]
+        max_value = cdf_lengths[idx] - 2
+        value = int(s) - int(offsets[idx])
+        raw_val = 0
+        if value < 0:
+            raw_val = -2 * value - 1
+            value = max_value
+        elif value >= max_value:
+            raw_val = 2 * (value - max_value)
+            value = max_value
+        syms.append((int(cdf[value]) & 0xFFFF, (int(cdf[value + 1]) - int(cdf[value])) & 0xFFFF, False))
+        if value == max_value:
+            n_bypass = 0
+            while (raw_val >> (n_bypass * BYPASS_PRECISION)) != 0:
+                n_bypass += 1
+            val = n_bypass
+            while val >= MAX_BYPASS_VAL:
+                syms.append((MAX_BYPASS_VAL, MAX_BYPASS_VAL + 1, True))
+                val -= MAX_BYPASS_VAL
+            syms.append((val, val + 1, True))
+            for j in range(n_bypass):
+                v = (raw_val >> (j * BYPASS_PRECISION)) & MAX_BYPASS_VAL
+                syms.append((v, v + 1, True))
+    return syms
+
+
+def rans_encode_with_indexes(symbols, indexes, cdfs, cdf_lengths, offsets) -> bytes:
+    syms = rans_symbolize(symbols, indexes, cdfs, cdf_lengths, offsets)
+    x = RANS64_L
+    words: List[int] = []  # emitted in reverse memory order
+    for start, rng, bypass in reversed(syms):
+        if not bypass:
+            x_max = ((RANS64_L >> PRECISION) << 32) * rng
+            if x >= x_max:
+                words.append(x & 0xFFFFFFFF)
+                x >>= 32
+            x = ((x // rng) << PRECISION) + (x % rng) + start
+        else:
+            freq = 1 << (16 - BYPASS_PRECISION)
+            x_max = ((RANS64_L >> 16) << 32) * freq
+            if x >= x_max:
+                words.append(x & 0xFFFFFFFF)
+                x >>= 32
+            x = ((x << BYPASS_PRECISION) | start) & M64
+    # flush: memory order word0 = low, word1 = high, then previously emitted words reversed
+    out = [x & 0xFFFFFFFF, (x >> 32) & 0xFFFFFFFF] + list(reversed(words))
+    return struct.pack('<%dI' % len(out), *out)
+
+
+def rans_decode_with_indexes(encoded: bytes, indexes, cdfs, cdf_lengths, offsets) -> List[int]:
+    n_words = len(encoded) // 4
+    words = struct.unpack('<%dI' % n_words, encoded[:4 * n_words])
+    x = words[0] | (words[1] << 32)
+    ptr = 2
+
+    def get_bits(nbits):
+        nonlocal x, ptr
+        val = x & ((1 << nbits) - 1)
+        x >>= nbits
+        if x < RANS64_L:
+            x = (x << 32) | words[ptr]
+            ptr += 1
+        return val
+
+    out = []
+    for idx in indexes:
+        cdf = cdfs[idx]
+        n = cdf_lengths[idx]
+        max_value = n - 2
+        cum = x & ((1 << PRECISION) - 1)
+        k = 0
+        while k < n and not (int(cdf[k]) > cum):
+            k += 1
+        s = k - 1
+        start = int(cdf[s])
+        rng = int(cdf[s + 1]) - start
+        x = rng * (x >> PRECISION) + (x & ((1 << PRECISION) - 1)) - start
+        if x < RANS64_L:
+            x = (x << 32) | words[ptr]
+            ptr += 1
+        value = s
+        if value == max_value:
+            val = get_bits(BYPASS_PRECISION)
+            n_bypass = val
+            while val == MAX_BYPASS_VAL:
+                val = get_bits(BYPASS_PRECISION)
+                n_bypass += val
+            raw_val = 0
+            for j in range(n_bypass):
+                val = get_bits(BYPASS_PRECISION)
+                raw_val |= val << (j * BYPASS_PRECISION)
+            value = raw_val >> 1
+            if raw_val & 1:
+                value = -value - 1
+            else:
+                value += max_value
+        out.append(value + int(offsets[idx]))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Factorized EntropyBottleneck (Appendix A.2 / A.3)
+# --------------------------------------------------------------------------------------
+
+class EntropyBottleneckOracle:
+    """Functional restatement of compressai.entropy_models.EntropyBottleneck.
+
+    Parameters are held in a plain dict with the reference state-dict names
+    (``_matrix{i}``, ``_bias{i}``, ``_factor{i}``, ``quantiles``;
+    ``scripts/transfer_weights.py:5-19`` confirms the names).
+    """
+
+    def __init__(self, channels: int, filters: Sequence[int] = (3, 3, 3, 3),
+                 init_scale: float = 10.0, tail_mass: float = 1e-9,
+                 likelihood_bound: float = 1e-9, generator: Optional[torch.Generator] = None):
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+        self.likelihood_bound = float(likelihood_bound)
+        F_ = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.filters) + 1))
+        p = {}
+        for i in range(len(self.filters) + 1):
+            init = np.log(np.expm1(1 / scale / F_[i + 1]))
+            p[f'_matrix{i}'] = torch.full((channels, F_[i + 1], F_[i]), float(init))
+            b = torch.empty(channels, F_[i + 1], 1)
+            b.uniform_(-0.5, 0.5, generator=generator)
+            p[f'_bias{i}'] = b
+            if i < len(self.filters):
+                p[f'_factor{i}'] = torch.zeros(channels, F_[i + 1], 1)
+        q = torch.tensor([-self.init_scale, 0.0, self.init_scale])
+        p['quantiles'] = q.repeat(channels, 1, 1)
+        self.params = p
+        t = np.log(2 / self.tail_mass - 1)
+        self.target = torch.tensor([-t, 0.0, t], dtype=torch.float32)
+        self._offset = None
+        self._quantized_cdf = None
+        self._cdf_length = None
+
+    def load(self, state: dict):
+        for k in list(self.params.keys()):
+            if k in state:
+                self.params[k] = state[k].detach().clone().float()
+
+    # -- density model ---------------------------------------------------------------
+    def medians(self) -> torch.Tensor:
+        return self.params['quantiles'][:, :, 1:2]
+
+    def logits_cumulative(self, v: torch.Tensor) -> torch.Tensor:
+        logits = v
+        n = len(self.filters)
+        for i in range(n + 1):
+            logits = torch.matmul(F.softplus(self.params[f'_matrix{i}']), logits)
+            logits = logits + self.params[f'_bias{i}']
+            if i < n:
+                logits = logits + torch.tanh(self.params[f'_factor{i}']) * torch.tanh(logits)
+        return logits
+
+    def likelihood(self, v: torch.Tensor):
+        lower = self.logits_cumulative(v - 0.5)
+        upper = self.logits_cumulative(v + 0.5)
+        sign = -torch.sign(lower + upper)
+        lik = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+        return lik, lower, upper
+
+    def forward(self, x: torch.Tensor, training: bool = False, generator=None):
+        """x (B,C,...) -> (y_hat, likelihood) in the input layout (eval: quantise)."""
+        perm = list(range(x.dim()))
+        perm[0], perm[1] = 1, 0
+        xp = x.permute(*perm).contiguous()
+        shape = xp.shape
+        values = xp.reshape(shape[0], 1, -1)
+        if training:
+            noise = torch.empty_like(values).uniform_(-0.5, 0.5, generator=generator)
+            outputs = values + noise
+        else:
+            m = self.medians()
+            outputs = torch.round(values - m) + m
+        lik, _, _ = self.likelihood(outputs)
+        if self.likelihood_bound > 0:
+            lik = torch.clamp(lik, min=self.likelihood_bound)
+        outputs = outputs.reshape(shape).permute(*perm).contiguous()
+        lik = lik.reshape(shape).permute(*perm).contiguous()
+        return outputs, lik
+
+    def loss(self) -> torch.Tensor:
+        logits = self.logits_cumulative(self.params['quantiles'])
+        return torch.abs(logits - self.target).sum()
+
+    # -- CDF tables ------------------------------------------------------------------
+    def update(self):
+        q = self.params['quantiles']
+        medians = q[:, 0, 1]
+        minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
+        maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
+        self._offset = -minima
+        pmf_start = medians - minima
+        pmf_length = maxima + minima + 1
+        max_length = int(pmf_length.max().item())
+        samples = torch.arange(max_length)
+        samples = samples[None, :] + pmf_start[:, None, None]
+        pmf, lower, upper = self.likelihood(samples)
+        pmf = pmf[:, 0, :]
+        tail = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+        cdf = torch.zeros((self.channels, max_length + 2), dtype=torch.int32)
+        for i in range(self.channels):
+            prob = torch.cat((pmf[i, :int(pmf_length[i])], tail[i]), dim=0)
+            c = pmf_to_quantized_cdf(prob.tolist(), PRECISION)
+            cdf[i, :len(c)] = torch.tensor(c, dtype=torch.int64).to(torch.int32)
+        self._quantized_cdf = cdf
+        self._cdf_length = (pmf_length + 2).int()
+        return True
+
+    # -- coding ------------------------------------------------------------------------
+    def symbols(self, x: torch.Tensor) -> torch.Tensor:
+        """x (B,C,H,W) -> int32 symbols = round(x - median_c) (half-to-even)."""
+        m = self.medians().reshape(1, -1, *([1] * (x.dim() - 2)))
+        return torch.round(x - m).int()
+
+    def indexes(self, size) -> torch.Tensor:
+        C = size[1]
+        view = [1] * len(size)
+        view[1] = -1
+        return torch.arange(C).view(*view).int().repeat(size[0], 1, *size[2:])
+
+    def compress(self, x: torch.Tensor, encode_fn=None) -> List[bytes]:
+        enc = encode_fn or rans_encode_with_indexes
+        sym = self.symbols(x)
+        idx = self.indexes(x.shape)
+        cdfs = self._quantized_cdf.tolist()
+        lens = self._cdf_length.tolist()
+        offs = self._offset.tolist()
+        return [enc(sym[b].reshape(-1).tolist(), idx[b].reshape(-1).tolist(), cdfs, lens, offs)
+                for b in range(x.shape[0])]
+
+    def decompress(self, strings: Sequence[bytes], size, decode_fn=None) -> torch.Tensor:
+        dec = decode_fn or rans_decode_with_indexes
+        out_size = (len(strings), self.channels, *size)
+        idx = self.indexes(out_size)
+        cdfs = self._quantized_cdf.tolist()
+        lens = self._cdf_length.tolist()
+        offs = self._offset.tolist()
+        out = torch.empty(out_size, dtype=torch.int32)
+        for b, s in enumerate(strings):
+            vals = dec(s, idx[b].reshape(-1).tolist(), cdfs, lens, offs)
+            out[b] = torch.tensor(vals, dtype=torch.int32).reshape(out_size[1:])
+        m = self.medians().reshape(1, -1, *([1] * len(size)))
+        return out.to(m.dtype) + m
+
+
+# --------------------------------------------------------------------------------------
+# Codec byte format (reference _autoencoders.py:539-584)
+# --------------------------------------------------------------------------------------
+
+def codec_encode(tile_u8: np.ndarray, enc_layers, eb: EntropyBottleneckOracle, encode_fn=None) -> bytes:
+    h, w, _ = tile_u8.shape
+    x = tile_to_input(tile_u8)
+    y, _ = analysis_forward(x, enc_layers)
+    return struct.pack('>QQ', h, w) + eb.compress(y, encode_fn)[0]
+
+
+def codec_decode(buf: bytes, dec_layers, eb: EntropyBottleneckOracle, decode_fn=None) -> np.ndarray:
+    L = len(dec_layers)
+    h, w = struct.unpack('>QQ', buf[:16])
+    size = (h // 2 ** L, w // 2 ** L)
+    yq = eb.decompress([buf[16:]], size, decode_fn)
+    x_r, _ = synthesis_forward(yq, dec_layers)
+    return output_to_tile(x_r[0])

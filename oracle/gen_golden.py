@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures under tests/golden/ by running the REFERENCE's own classes.
+
+Run only in the build container (``/root/reference`` does not exist on the GPU box):
+
+    python oracle/gen_golden.py
+
+What is executed from the reference: ``src/models/tasks/_autoencoders.py`` loaded by
+file path, with the third-party names that are absent from this image
+(``compressai``, ``numcodecs``) stubbed in ``sys.modules``.  The
+reference's ``Analyzer`` / ``Synthesizer`` / ``DownsamplingUnit`` / ``UpsamplingUnit``
+/ ``initialize_weights`` therefore run unmodified; the stub ``GDN`` is OUR restatement
+(oracle/cae_oracle.py) because compressai's is absent, so in the GDN fixtures the
+conv / conv-transpose layers and the unit wiring are reference-pinned while the GDN
+arithmetic is "parity unpinned".  Fixtures with ``act=None`` are reference-pinned end
+to end.
+
+Only data (inputs, weights, expected outputs) is written; no reference source is copied.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import cae_oracle as O  # noqa: E402
+from cnn_autoencoder_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+REF = '/root/reference/src/models/tasks/_autoencoders.py'
+
+
+class StubGDN(nn.Module):
+    """Stand-in for compressai.layers.GDN with the same ctor signature and parameter names."""
+
+    def __init__(self, in_channels, inverse=False, beta_min=1e-6, gamma_init=0.1):
+        super().__init__()
+        self.inverse = bool(inverse)
+        self.beta_min = float(beta_min)
+        b, g = O.gdn_init_params(in_channels, gamma_init)
+        self.beta = nn.Parameter(b)
+        self.gamma = nn.Parameter(g)
+
+    def forward(self, x):
+        return O.gdn_forward(x, self.beta, self.gamma, self.inverse, self.beta_min)
+
+
+def load_reference():
+    for name in ['compressai', 'compressai.layers', 'compressai.entropy_models', 'numcodecs',
+                 'numcodecs.abc', 'numcodecs.compat']:
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules['compressai'].ans = None
+    sys.modules['compressai.layers'].GDN = StubGDN
+    sys.modules['compressai.entropy_models'].EntropyBottleneck = object
+    sys.modules['numcodecs.abc'].Codec = object
+    sys.modules['numcodecs.compat'].ndarray_copy = None
+    sys.modules['numcodecs.compat'].ensure_contiguous_ndarray = None
+    spec = importlib.util.spec_from_file_location('ref_autoencoders', REF)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def layer_outputs(seq, x):
+    outs = []
+    fx = x
+    for unit in seq:
+        fx = unit(fx)
+        outs.append(fx)
+    return outs
+
+
+def stats(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
+
+
+def make_case(ref, name, cfg, tile, seed, store_weights, store_layers):
+    """Run the reference Analyzer/Synthesizer on `tile` with synthetic_state(cfg, seed)."""
+    state = synth.synthetic_state(cfg, seed=seed)
+    kw = {k: cfg[k] for k in ['channels_org', 'channels_net', 'channels_bn', 'compression_level',
+                              'channels_expansion', 'kernel_size', 'groups', 'batch_norm', 'dropout',
+                              'bias', 'use_residual', 'act_layer_type']}
+    enc = ref.Analyzer(**kw)
+    dec = ref.Synthesizer(**kw)
+    missing = enc.load_state_dict(state['encoder'], strict=True)
+    missing = dec.load_state_dict(state['decoder'], strict=True)
+    enc.eval()
+    dec.eval()
+    out = {}
+    with torch.no_grad():
+        x = O.tile_to_input(tile)
+        enc_outs = layer_outputs(enc.analysis_track, x)
+        y = enc(x)
+        assert torch.equal(y, enc_outs[-1])
+        # entropy model is ours (unpinned): quantise with the oracle's medians (all zero at init)
+        yq = torch.round(y)
+        x_r, brg = dec(yq)
+        dec_outs = layer_outputs(dec.synthesis_track, yq)
+        assert torch.equal(x_r[0], dec_outs[-1]) and torch.equal(brg[-1], dec_outs[-1])
+        assert all(t is None for t in x_r[1:])
+        u8 = O.output_to_tile(x_r[0][0])
+    out['tile'] = tile
+    out['y'] = y.numpy()
+    out['x_r'] = x_r[0].numpy()
+    out['x_r_u8'] = u8
+    for i, t in enumerate(enc_outs):
+        out[f'enc_stats_{i}'] = stats(t)
+        if store_layers:
+            out[f'enc_out_{i}'] = t.numpy()
+    for i, t in enumerate(dec_outs):
+        out[f'dec_stats_{i}'] = stats(t)
+        if store_layers:
+            out[f'dec_out_{i}'] = t.numpy()
+    if store_weights:
+        for k, v in state['encoder'].items():
+            out['encoder/' + k] = v.numpy()
+        for k, v in state['decoder'].items():
+            out['decoder/' + k] = v.numpy()
+    out['cfg_json'] = np.frombuffer(json.dumps(dict(cfg, seed=seed)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **out)
+    print(name, 'y', tuple(y.shape), 'x_r', tuple(x_r[0].shape),
+          '|y|max %.3f' % y.abs().max().item(), 'size %.1f KB' % (os.path.getsize(os.path.join(GOLD, name + '.npz')) / 1024))
+
+
+def make_init_fixture(ref):
+    """Pins initialize_weights (_autoencoders.py:37-42) and the state-dict key list."""
+    torch.manual_seed(0)
+    enc = ref.Analyzer(3, 8, 16, 3, act_layer_type='GDN')
+    dec = ref.Synthesizer(3, 8, 16, 3, act_layer_type='GDN')
+    out = {}
+    for k, v in enc.state_dict().items():
+        out['encoder/' + k] = v.numpy()
+    for k, v in dec.state_dict().items():
+        out['decoder/' + k] = v.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'ref_init_seed0.npz'), **out)
+    print('ref_init_seed0', list(out.keys()))
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    ref = load_reference()
+    small = dict(synth.CANONICAL, channels_net=8, channels_bn=16, compression_level=3)
+    small_noact = dict(small, act_layer_type=None)
+    mnist = dict(small, channels_org=1)
+    k5 = dict(small, kernel_size=5, bias=True)
+    rng = np.random.default_rng(99)
+
+    make_init_fixture(ref)
+    # reference-pinned end to end (no GDN): even and ragged sizes
+    make_case(ref, 'noact_small_40x56', small_noact, synth.histo_tile(40, 1, 56), 11, True, True)
+    make_case(ref, 'noact_small_37x45', small_noact, rng.integers(0, 256, (37, 45, 3), dtype=np.uint8), 12, True, True)
+    # GDN variant (conv reference-pinned, GDN restated)
+    make_case(ref, 'gdn_small_40x56', small, synth.histo_tile(40, 2, 56), 13, True, True)
+    make_case(ref, 'gdn_small_37x45', small, rng.integers(0, 256, (37, 45, 3), dtype=np.uint8), 14, True, True)
+    make_case(ref, 'gdn_mnist_32x32', mnist, synth.mnist_like(1)[0], 15, True, True)
+    make_case(ref, 'gdn_k5bias_48x48', k5, synth.histo_tile(48, 3), 16, True, True)
+    # canonical 128/192/L4 (weights rebuilt from the seed by synth.synthetic_state)
+    make_case(ref, 'gdn_canonical_64x64', synth.CANONICAL, synth.histo_tile(64, 4), 17, False, False)
+    make_case(ref, 'gdn_canonical_96x80', synth.CANONICAL, rng.integers(0, 256, (96, 80, 3), dtype=np.uint8), 18, False, False)
+
+
+if __name__ == '__main__':
+    main()
