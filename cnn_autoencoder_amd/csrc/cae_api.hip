@@ -1,0 +1,535 @@
+// Host side of libcae_hip.so: model handle, weight packing, kernel dispatch (see include/cae_hip.h).
+#include "cae_hip.h"
+#include "cae_internal.hpp"
+#include "cae_kernels.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace cae {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(CAE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+static int round_ct(int c) {
+    const int t = (c + 31) / 32;
+    if (t <= 1) return 1;
+    if (t <= 2) return 2;
+    if (t <= 4) return 4;
+    if (t <= 6) return 6;
+    return -1;
+}
+
+// ---- packing -----------------------------------------------------------------------------------
+// weights -> [chunk][ky][kx][ct][lane][j]:  value W(cout = 32ct + (lane&31), cin = 8chunk + 4(lane>>5) + j, ky, kx)
+static std::vector<float> pack_weights(const float *w, bool transposed, int cin, int cout, int ks, int ct) {
+    const int chunks = (cin + 7) / 8;
+    std::vector<float> out((size_t)chunks * ks * ks * ct * 256, 0.0f);
+    size_t o = 0;
+    for (int c = 0; c < chunks; ++c)
+        for (int ky = 0; ky < ks; ++ky)
+            for (int kx = 0; kx < ks; ++kx)
+                for (int t = 0; t < ct; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j, ++o) {
+                            const int co = 32 * t + (lane & 31);
+                            const int ci = 8 * c + 4 * (lane >> 5) + j;
+                            if (co < cout && ci < cin) {
+                                // conv: (cout,cin,k,k); transposed conv: (cin,cout,k,k)
+                                const size_t idx = transposed ? (((size_t)ci * cout + co) * ks + ky) * ks + kx
+                                                              : (((size_t)co * cin + ci) * ks + ky) * ks + kx;
+                                out[o] = w[idx];
+                            }
+                        }
+    return out;
+}
+
+// gamma -> [jt][co][q][lane][jj]: value G(c = 32co + (lane&31), j = 32jt + row(4q+jj) + 4(lane>>5))
+static std::vector<float> pack_gamma(const float *g, int C, int ct) {
+    std::vector<float> out((size_t)ct * ct * 4 * 256, 0.0f);
+    size_t o = 0;
+    for (int jt = 0; jt < ct; ++jt)
+        for (int co = 0; co < ct; ++co)
+            for (int q = 0; q < 4; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int jj = 0; jj < 4; ++jj, ++o) {
+                        const int s = 4 * q + jj;
+                        const int c = 32 * co + (lane & 31);
+                        const int j = 32 * jt + (s & 3) + 8 * (s >> 2) + 4 * (lane >> 5);
+                        if (c < C && j < C) out[o] = g[(size_t)c * C + j];
+                    }
+    return out;
+}
+
+static int upload(const std::vector<float> &v, float **dev) {
+    if (*dev) {
+        (void)hipFree(*dev);
+        *dev = nullptr;
+    }
+    HIP_TRY(hipMalloc((void **)dev, v.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*dev, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return CAE_OK;
+}
+
+int Model::ensure_ws(int which, size_t bytes) {
+    if (ws_bytes[which] >= bytes) return CAE_OK;
+    if (ws[which]) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(ws[which]);
+        ws[which] = nullptr;
+        ws_bytes[which] = 0;
+    }
+    bytes = (bytes + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+    HIP_TRY(hipMalloc(&ws[which], bytes));
+    ws_bytes[which] = bytes;
+    return CAE_OK;
+}
+
+int Model::ensure_device() {
+    if (!zero) {
+        HIP_TRY(hipMalloc((void **)&zero, 256));
+        HIP_TRY(hipMemset(zero, 0, 256));
+    }
+    if (medians_dirty && ent.channels > 0) {
+        int rc = upload(ent.medians, &medians_dev);
+        if (rc) return rc;
+        medians_dirty = false;
+    }
+    return CAE_OK;
+}
+
+Model::~Model() {
+    for (auto *tr : {&enc, &dec})
+        for (auto &l : *tr) {
+            if (l.wp) (void)hipFree(l.wp);
+            if (l.bias) (void)hipFree(l.bias);
+            if (l.gp) (void)hipFree(l.gp);
+            if (l.beta) (void)hipFree(l.beta);
+        }
+    for (int i = 0; i < 3; ++i)
+        if (ws[i]) (void)hipFree(ws[i]);
+    if (zero) (void)hipFree(zero);
+    if (medians_dev) (void)hipFree(medians_dev);
+}
+
+// ---- kernel dispatch ---------------------------------------------------------------------------
+template <int KS, int CT, bool GDN>
+static int launch_conv_t(const LayerArgs &a, hipStream_t st) {
+    constexpr int NW = 4;
+    constexpr int WH = 2 * 16 + KS - 2;
+    constexpr int HALO_INSTR = (2 * NW * WH * 2 + 63) / 64;
+    constexpr int CONV_STAGE = KS * CT * 1024 + HALO_INSTR * 1024;
+    constexpr int G_BYTES = GDN ? CT * 4096 : 0;
+    constexpr int LDS = 2 * (CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES);
+    auto kern = conv_s2_kernel<KS, CT, NW, GDN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+template <int KS, int CT, bool GDN>
+static int launch_deconv_t(const LayerArgs &a, hipStream_t st) {
+    constexpr int NW = 4;
+    constexpr int P = KS / 2;
+    constexpr int WH = 32 + (KS - 1 - P) / 2 + (P + 1) / 2;
+    constexpr int HALO_INSTR = (NW * WH * 2 + 63) / 64;
+    constexpr int CONV_STAGE = KS * CT * 1024 + HALO_INSTR * 1024;
+    constexpr int G_BYTES = GDN ? CT * 4096 : 0;
+    constexpr int LDS = 2 * (CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES);
+    auto kern = deconv_s2_kernel<KS, CT, NW, GDN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+template <int CT, bool INV>
+static int launch_gdn_t(const LayerArgs &a, hipStream_t st) {
+    constexpr int NW = 4;
+    constexpr int LDS = 2 * CT * 4096;
+    auto kern = gdn_c8_kernel<CT, NW, INV>;
+    const int hw = a.H * a.W;
+    const unsigned grid = (unsigned)((size_t)a.N * ((hw + NW * 32 - 1) / (NW * 32)));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+#define DISPATCH_CT(FN, KS_, GDN_)                                               \
+    switch (ct) {                                                                \
+        case 1: return FN<KS_, 1, GDN_>(a, st);                                  \
+        case 2: return FN<KS_, 2, GDN_>(a, st);                                  \
+        case 4: return FN<KS_, 4, GDN_>(a, st);                                  \
+        case 6: return FN<KS_, 6, GDN_>(a, st);                                  \
+        default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct); \
+    }
+
+int launch_conv(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
+    if (ks == 3) {
+        if (gdn) { DISPATCH_CT(launch_conv_t, 3, true) } else { DISPATCH_CT(launch_conv_t, 3, false) }
+    } else if (ks == 5) {
+        if (gdn) { DISPATCH_CT(launch_conv_t, 5, true) } else { DISPATCH_CT(launch_conv_t, 5, false) }
+    }
+    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+}
+
+int launch_deconv(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
+    if (ks == 3) {
+        if (gdn) { DISPATCH_CT(launch_deconv_t, 3, true) } else { DISPATCH_CT(launch_deconv_t, 3, false) }
+    } else if (ks == 5) {
+        if (gdn) { DISPATCH_CT(launch_deconv_t, 5, true) } else { DISPATCH_CT(launch_deconv_t, 5, false) }
+    }
+    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+}
+
+int launch_gdn(int ct, bool inverse, const LayerArgs &a, hipStream_t st) {
+    switch (ct) {
+        case 1: return inverse ? launch_gdn_t<1, true>(a, st) : launch_gdn_t<1, false>(a, st);
+        case 2: return inverse ? launch_gdn_t<2, true>(a, st) : launch_gdn_t<2, false>(a, st);
+        case 4: return inverse ? launch_gdn_t<4, true>(a, st) : launch_gdn_t<4, false>(a, st);
+        case 6: return inverse ? launch_gdn_t<6, true>(a, st) : launch_gdn_t<6, false>(a, st);
+    }
+    return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct);
+}
+
+static unsigned ew_grid(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (unsigned)std::min<size_t>(std::max<size_t>(b, 1), 256 * 8 * 4);
+}
+
+}  // namespace cae
+
+using namespace cae;
+
+extern "C" {
+
+int cae_version(void) { return 1; }
+const char *cae_last_error(void) { return g_last_error.c_str(); }
+void cae_free(void *p) { free(p); }
+
+int cae_model_create(int channels_org, int channels_net, int channels_bn, int compression_level, int kernel_size,
+                     cae_model_t **out) {
+    if (!out) return fail(CAE_ERR_ARG, "out is NULL");
+    if (channels_org < 1 || channels_net < 1 || channels_bn < 1 || compression_level < 1)
+        return fail(CAE_ERR_ARG, "bad model dimensions");
+    if (kernel_size != 3 && kernel_size != 5)
+        return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", kernel_size);
+    if (round_ct(channels_net) < 0 || round_ct(channels_bn) < 0 || round_ct(channels_org) < 0)
+        return fail(CAE_ERR_UNSUPPORTED, "more than 192 channels per layer not supported");
+    Model *m = new Model();
+    m->c_org = channels_org;
+    m->c_net = channels_net;
+    m->c_bn = channels_bn;
+    m->L = compression_level;
+    m->ks = kernel_size;
+    m->enc.resize(m->L);
+    m->dec.resize(m->L);
+    // no HIP call here: the host entropy coder of a handle works without a GPU; device
+    // state is created on first device use (Model::ensure_device)
+    *out = reinterpret_cast<cae_model_t *>(m);
+    return CAE_OK;
+}
+
+void cae_model_destroy(cae_model_t *mm) {
+    if (mm) {
+        (void)hipDeviceSynchronize();
+        delete reinterpret_cast<Model *>(mm);
+    }
+}
+
+int cae_model_set_layer(cae_model_t *mm, int track, int index, int cin, int cout, const float *w, const float *bias,
+                        const float *beta, const float *gamma) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !w) return fail(CAE_ERR_ARG, "NULL model or weight");
+    if (track != CAE_ANALYSIS && track != CAE_SYNTHESIS) return fail(CAE_ERR_ARG, "bad track %d", track);
+    if (index < 0 || index >= m->L) return fail(CAE_ERR_ARG, "layer index %d out of range", index);
+    if ((beta == nullptr) != (gamma == nullptr)) return fail(CAE_ERR_ARG, "beta and gamma must come together");
+    const int ct = round_ct(cout);
+    if (ct < 0 || round_ct(cin) < 0) return fail(CAE_ERR_UNSUPPORTED, "more than 192 channels not supported");
+    std::lock_guard<std::mutex> lk(m->mu);
+    Layer &l = (track == CAE_ANALYSIS ? m->enc : m->dec)[index];
+    l.cin = cin;
+    l.cout = cout;
+    l.ct = ct;
+    l.chunks = (cin + 7) / 8;
+    l.set = true;
+    int rc = upload(pack_weights(w, track == CAE_SYNTHESIS, cin, cout, m->ks, ct), &l.wp);
+    if (rc) return rc;
+    if (bias) {
+        std::vector<float> b(ct * 32, 0.0f);
+        std::copy(bias, bias + cout, b.begin());
+        if ((rc = upload(b, &l.bias))) return rc;
+    } else if (l.bias) {
+        (void)hipFree(l.bias);
+        l.bias = nullptr;
+    }
+    l.gdn = beta != nullptr;
+    if (l.gdn) {
+        std::vector<float> b(ct * 32, 1.0f);
+        std::copy(beta, beta + cout, b.begin());
+        if ((rc = upload(b, &l.beta))) return rc;
+        if ((rc = upload(pack_gamma(gamma, cout, ct), &l.gp))) return rc;
+    }
+    return CAE_OK;
+}
+
+int cae_model_set_entropy(cae_model_t *mm, int channels, int cdf_stride, const int32_t *cdf, const int32_t *cdf_length,
+                          const int32_t *offset, const float *medians) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !cdf || !cdf_length || !offset || !medians) return fail(CAE_ERR_ARG, "NULL argument");
+    if (channels != m->c_bn) return fail(CAE_ERR_ARG, "entropy model has %d channels, model %d", channels, m->c_bn);
+    for (int c = 0; c < channels; ++c) {
+        if (cdf_length[c] < 2 || cdf_length[c] > cdf_stride)
+            return fail(CAE_ERR_ARG, "cdf_length[%d]=%d out of range", c, cdf_length[c]);
+    }
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->ent.channels = channels;
+    m->ent.stride = cdf_stride;
+    m->ent.cdf.assign(cdf, cdf + (size_t)channels * cdf_stride);
+    m->ent.len.assign(cdf_length, cdf_length + channels);
+    m->ent.off.assign(offset, offset + channels);
+    m->ent.medians.assign(medians, medians + channels);
+    m->ent.build_tables();
+    m->medians_dirty = true;
+    return CAE_OK;
+}
+
+int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int w, float *latents, void *stream) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !tiles || !latents) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 2 || w < 2) return fail(CAE_ERR_ARG, "bad tile batch %dx%dx%d", n, h, w);
+    if (fmt != CAE_FMT_U8_HWC && fmt != CAE_FMT_F32_NCHW) return fail(CAE_ERR_ARG, "bad pixel format %d", fmt);
+    for (auto &l : m->enc)
+        if (!l.set) return fail(CAE_ERR_ARG, "analysis layer not set");
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(m->mu);
+    int rc;
+    if ((rc = m->ensure_device())) return rc;
+
+    // workspace: ws[0] = converted input, ws[1]/ws[2] ping-pong
+    const int p0 = (m->c_org + 7) / 8;
+    size_t in_bytes = (size_t)n * p0 * h * w * 32;
+    size_t maxact = 0;
+    {
+        int ch = h, cw = w;
+        for (int i = 0; i + 1 < m->L; ++i) {
+            ch = (ch + 1) / 2;
+            cw = (cw + 1) / 2;
+            maxact = std::max(maxact, (size_t)n * m->enc[i].ct * 4 * ch * cw * 32);
+        }
+    }
+    if ((rc = m->ensure_ws(0, in_bytes))) return rc;
+    if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
+
+    const size_t tot = (size_t)n * p0 * h * w;
+    if (fmt == CAE_FMT_U8_HWC)
+        hipLaunchKernelGGL(u8hwc_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint8_t *)tiles,
+                           (float *)m->ws[0], n, h, w, m->c_org, p0);
+    else
+        hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)tiles,
+                           (float *)m->ws[0], n, m->c_org, h * w, p0);
+    HIP_TRY(hipGetLastError());
+
+    const float *cur = (const float *)m->ws[0];
+    int cur_planes = p0, ch = h, cw = w;
+    for (int i = 0; i < m->L; ++i) {
+        const Layer &l = m->enc[i];
+        const bool last = i == m->L - 1;
+        LayerArgs a{};
+        a.in = cur;
+        a.out = last ? (void *)latents : m->ws[1 + (i & 1)];
+        a.wp = l.wp;
+        a.bias = l.bias;
+        a.gp = l.gp;
+        a.beta = l.beta;
+        a.zero = m->zero;
+        a.N = n;
+        a.H = ch;
+        a.W = cw;
+        a.OH = (ch + 1) / 2;
+        a.OW = (cw + 1) / 2;
+        a.in_planes = cur_planes;
+        a.cci = l.chunks;
+        a.out_planes = l.ct * 4;
+        a.cout = l.cout;
+        a.tiles_x = (a.OW + 15) / 16;
+        a.tiles_y = (a.OH + 7) / 8;
+        a.outfmt = last ? OUT_NCHW : OUT_C8;
+        if ((rc = launch_conv(m->ks, l.ct, l.gdn, a, st))) return rc;
+        cur = (const float *)a.out;
+        cur_planes = l.ct * 4;
+        ch = a.OH;
+        cw = a.OW;
+    }
+    return CAE_OK;
+}
+
+int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, void *out, int fmt,
+                  float *const *bridges, void *stream) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !latents || !out) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || lh < 1 || lw < 1) return fail(CAE_ERR_ARG, "bad latent batch %dx%dx%d", n, lh, lw);
+    if (fmt != CAE_FMT_U8_HWC && fmt != CAE_FMT_F32_NCHW) return fail(CAE_ERR_ARG, "bad pixel format %d", fmt);
+    for (auto &l : m->dec)
+        if (!l.set) return fail(CAE_ERR_ARG, "synthesis layer not set");
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(m->mu);
+    int rc;
+    if ((rc = m->ensure_device())) return rc;
+
+    const int p0 = (m->c_bn + 7) / 8;
+    size_t in_bytes = (size_t)n * p0 * lh * lw * 32;
+    size_t maxact = 0;
+    {
+        int ch = lh, cw = lw;
+        for (int i = 0; i + 1 < m->L; ++i) {
+            ch *= 2;
+            cw *= 2;
+            maxact = std::max(maxact, (size_t)n * m->dec[i].ct * 4 * ch * cw * 32);
+        }
+    }
+    if ((rc = m->ensure_ws(0, in_bytes))) return rc;
+    if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
+
+    const size_t tot = (size_t)n * p0 * lh * lw;
+    hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (float *)m->ws[0], n, m->c_bn,
+                       lh * lw, p0);
+    HIP_TRY(hipGetLastError());
+
+    const float *cur = (const float *)m->ws[0];
+    int cur_planes = p0, ch = lh, cw = lw;
+    for (int i = 0; i < m->L; ++i) {
+        const Layer &l = m->dec[i];
+        const bool last = i == m->L - 1;
+        LayerArgs a{};
+        a.in = cur;
+        a.out = last ? out : m->ws[1 + (i & 1)];
+        a.wp = l.wp;
+        a.bias = l.bias;
+        a.gp = l.gp;
+        a.beta = l.beta;
+        a.zero = m->zero;
+        a.N = n;
+        a.H = ch;
+        a.W = cw;
+        a.OH = 2 * ch;
+        a.OW = 2 * cw;
+        a.in_planes = cur_planes;
+        a.cci = l.chunks;
+        a.out_planes = l.ct * 4;
+        a.cout = l.cout;
+        a.tiles_x = (cw + 31) / 32;
+        a.tiles_y = (ch + 3) / 4;
+        a.outfmt = last ? (fmt == CAE_FMT_U8_HWC ? OUT_U8HWC : OUT_NCHW) : OUT_C8;
+        if ((rc = launch_deconv(m->ks, l.ct, l.gdn, a, st))) return rc;
+        if (!last && bridges && bridges[i]) {
+            const size_t t2 = (size_t)n * l.cout * a.OH * a.OW;
+            hipLaunchKernelGGL(c8_to_nchw_kernel, dim3(ew_grid(t2)), dim3(256), 0, st, (const float *)a.out, bridges[i],
+                               n, l.cout, a.OH * a.OW, l.ct * 4);
+            HIP_TRY(hipGetLastError());
+        }
+        cur = (const float *)a.out;
+        cur_planes = l.ct * 4;
+        ch = a.OH;
+        cw = a.OW;
+    }
+    return CAE_OK;
+}
+
+int cae_gdn_forward(cae_model_t *mm, int track, int index, const float *x, int n, int h, int w, float *y, void *stream) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !x || !y) return fail(CAE_ERR_ARG, "NULL argument");
+    if (track != CAE_ANALYSIS && track != CAE_SYNTHESIS) return fail(CAE_ERR_ARG, "bad track %d", track);
+    if (index < 0 || index >= m->L) return fail(CAE_ERR_ARG, "layer index %d out of range", index);
+    if (n < 1 || h < 1 || w < 1) return fail(CAE_ERR_ARG, "bad tensor shape");
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const Layer &l = (track == CAE_ANALYSIS ? m->enc : m->dec)[index];
+    if (!l.set || !l.gdn) return fail(CAE_ERR_ARG, "layer has no GDN");
+    const int planes = l.ct * 4;
+    int rc;
+    if ((rc = m->ensure_ws(0, (size_t)n * planes * h * w * 32))) return rc;
+    const size_t tot = (size_t)n * planes * h * w;
+    hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, x, (float *)m->ws[0], n, l.cout, h * w,
+                       planes);
+    HIP_TRY(hipGetLastError());
+    LayerArgs a{};
+    a.in = (const float *)m->ws[0];
+    a.out = y;
+    a.gp = l.gp;
+    a.beta = l.beta;
+    a.N = n;
+    a.H = h;
+    a.W = w;
+    a.OH = h;
+    a.OW = w;
+    a.in_planes = planes;
+    a.out_planes = planes;
+    a.cout = l.cout;
+    a.outfmt = OUT_NCHW;
+    return launch_gdn(l.ct, track == CAE_SYNTHESIS, a, st);
+}
+
+int cae_quantize(cae_model_t *mm, const float *latents, int n, int hw, int32_t *symbols, void *stream) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !latents || !symbols) return fail(CAE_ERR_ARG, "NULL argument");
+    if (m->ent.channels == 0) return fail(CAE_ERR_ARG, "entropy model not set");
+    if (n < 1 || hw < 1) return fail(CAE_ERR_ARG, "bad shape");
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        int rc = m->ensure_device();
+        if (rc) return rc;
+    }
+    const size_t total = (size_t)n * m->c_bn * hw;
+    hipLaunchKernelGGL(quantize_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, latents,
+                       m->medians_dev, symbols, m->c_bn, hw, total);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_dequantize(cae_model_t *mm, const int32_t *symbols, int n, int hw, float *latents, void *stream) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !latents || !symbols) return fail(CAE_ERR_ARG, "NULL argument");
+    if (m->ent.channels == 0) return fail(CAE_ERR_ARG, "entropy model not set");
+    if (n < 1 || hw < 1) return fail(CAE_ERR_ARG, "bad shape");
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        int rc = m->ensure_device();
+        if (rc) return rc;
+    }
+    const size_t total = (size_t)n * m->c_bn * hw;
+    hipLaunchKernelGGL(dequantize_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, symbols,
+                       m->medians_dev, latents, m->c_bn, hw, total);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// Internal types of libcae_hip.so (not part of the ABI).
+#pragma once
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <mutex>
+#include <vector>
+
+namespace cae {
+
+int fail(int code, const char *fmt, ...);
+
+struct Layer {
+    bool set = false;
+    int cin = 0, cout = 0, ct = 0, chunks = 0;
+    bool gdn = false;
+    float *wp = nullptr;    // packed weights (device)
+    float *bias = nullptr;  // [ct*32] (device) or null
+    float *gp = nullptr;    // packed gamma (device)
+    float *beta = nullptr;  // [ct*32] (device)
+};
+
+// Integer tables of the factorized entropy model + per-row encoder constants.
+struct EntropyTables {
+    int channels = 0, stride = 0;
+    std::vector<int32_t> cdf, len, off;
+    std::vector<float> medians;
+    // encoder: per (row, value) exact-division constants (ryg_rans "Rans64EncSymbol" form)
+    struct EncSym {
+        uint64_t rcp_freq;   // fixed-point reciprocal
+        uint32_t freq;
+        uint32_t bias;
+        uint32_t cmpl_freq;  // (1 << 16) - freq
+        uint32_t rcp_shift;
+    };
+    std::vector<EncSym> enc;  // [channels * stride]
+    void build_tables();
+};
+
+struct Model {
+    int c_org = 0, c_net = 0, c_bn = 0, L = 0, ks = 3;
+    std::vector<Layer> enc, dec;
+    EntropyTables ent;
+    float *medians_dev = nullptr;
+    bool medians_dirty = false;
+    float *zero = nullptr;
+    void *ws[3] = {nullptr, nullptr, nullptr};
+    size_t ws_bytes[3] = {0, 0, 0};
+    std::mutex mu;
+    int ensure_ws(int which, size_t bytes);
+    int ensure_device();
+    ~Model();
+};
+
+}  // namespace cae

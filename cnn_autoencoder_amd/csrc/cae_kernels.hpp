@@ -1,0 +1,556 @@
+// CDNA4 (gfx950) kernels of the convolutional-autoencoder hot path.
+//
+// Data layout in HBM ("C8"): activations between layers are fp32 [N][P][H][W][8], P = planes of
+// 8 channels.  One plane of one image is an H x W picture of 32-byte pixels, so
+//   * the input halo of an (8-channel chunk, kernel-row) stage is a set of contiguous row
+//     segments that LDS-DMA (global_load_lds_dwordx4) copies straight into LDS, reflect padding
+//     resolved in the per-lane SOURCE address (no im2col, no padded copy in HBM);
+//   * a 32x32 MFMA accumulator tile (rows = output channels, columns = pixels on the lanes)
+//     stores as 16-byte vectors that land in 512-byte contiguous runs.
+//
+// Contraction: v_mfma_f32_32x32x2_f32 (exact fp32, fmaf-chain numerics).  A = packed weights
+// (32 output channels x 2 k), B = activations (2 k x 32 pixels).  Each ds_read_b128 of either
+// operand feeds four consecutive MFMA k-steps (lane half h carries channels 4h..4h+3 of the
+// chunk), so LDS traffic is ~20 B/clk/CU: the kernels are MFMA-issue bound by construction.
+//
+// GDN / IGDN are fused as an epilogue: the conv accumulators (channel rows x pixel lanes) are
+// squared in registers and fed back as the B operand of a second MFMA chain against the packed
+// gamma matrix ("accumulator tile as the next MFMA's operand"), so y never leaves registers
+// between the convolution and the normalisation.
+//
+// Reference semantics implemented (file:line under /root/reference/src/models/tasks):
+//   conv_s2_kernel    nn.Conv2d(k, stride 2, padding k//2, padding_mode='reflect')
+//                     _autoencoders.py:78-85 (+ GDN :29-30)
+//   deconv_s2_kernel  nn.ConvTranspose2d(k, stride 2, padding k//2, output_padding 1)
+//                     _autoencoders.py:204-211 (+ IGDN :29-30), u8 epilogue :576-580
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum OutFmt { OUT_C8 = 0, OUT_NCHW = 1, OUT_U8HWC = 2 };
+
+struct LayerArgs {
+    const float *in;    // C8 [N][in_planes][H][W][8]
+    void *out;          // C8 [N][out_planes][OH][OW][8] | NCHW float | HWC uint8
+    const float *wp;    // packed weights  [chunk][ky][kx][ct][64 lanes][4]
+    const float *bias;  // [CT*32] (zero padded) or nullptr
+    const float *gp;    // packed gamma    [jt][co][q][64 lanes][4]
+    const float *beta;  // [CT*32] (padding = 1)
+    const float *zero;  // >= 64 B of zeros in HBM (deconv: out-of-range halo source)
+    int N, H, W, OH, OW;
+    int in_planes;      // plane stride of the input buffer
+    int cci;            // number of 8-channel input chunks actually contracted
+    int out_planes;     // plane stride of a C8 output buffer
+    int cout;           // real number of output channels (NCHW / U8 epilogues)
+    int tiles_x, tiles_y;
+    int outfmt;
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * n - 2 - i : i;
+    i = i < 0 ? 0 : i;
+    return i >= n ? n - 1 : i;
+}
+
+// 16-byte LDS-DMA: lane l copies 16 B from its own global address to lds_wave_base + 16*l.
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// row of a 32x32 accumulator register: row = (r&3) + 8*(r>>2) + 4*h
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
+
+template <int CT>
+__device__ __forceinline__ void init_acc(f32x16 (&acc)[CT], const float *vec, int h, float fill) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = vec ? vec[32 * ct + acc_row(r) + 4 * h] : fill;
+}
+
+// ---- fused GDN / IGDN on the accumulators ---------------------------------------------------
+// y[ct] : CT accumulator tiles (rows = channels 32ct.., cols = this wave's 32 pixels).
+// Runs CT staged pieces of the packed gamma through the double buffer.  On entry piece 0 has
+// been issued into buffer (sc & 1); on exit `tail(nxt)` has been called once to prefetch whatever
+// follows.  y is replaced by y * rsqrt(norm) (GDN) or y * sqrt(norm) (IGDN).
+template <int CT, int NW, bool INVERSE, int STAGE_BYTES, class Tail>
+__device__ __forceinline__ void gdn_stages(f32x16 (&y)[CT], const LayerArgs &p, char *smem, int &sc,
+                                           int wave, int lane, Tail tail) {
+    constexpr int G_BYTES = CT * 4096;
+    const int h = lane >> 5;
+    f32x16 nrm[CT];
+    init_acc<CT>(nrm, p.beta, h, 1.0f);
+#pragma unroll
+    for (int jt = 0; jt < CT; ++jt) {
+        wait_vm0();
+        __syncthreads();
+        char *cur = smem + (sc & 1) * STAGE_BYTES;
+        char *nxt = smem + ((sc + 1) & 1) * STAGE_BYTES;
+        if (jt + 1 < CT) {
+            const char *src = (const char *)p.gp + (size_t)(jt + 1) * G_BYTES;
+#pragma unroll
+            for (int i = 0; i < (CT * 4 + NW - 1) / NW; ++i) {
+                const int j = wave + i * NW;
+                if (j < CT * 4) glds16(src + j * 1024 + lane * 16, nxt + j * 1024);
+            }
+        } else {
+            tail(nxt);
+        }
+        const char *gb = cur + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 g[CT];
+#pragma unroll
+            for (int co = 0; co < CT; ++co) g[co] = *(const f32x4 *)(gb + (co * 4 + q) * 1024);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float v = y[jt][4 * q + jj];
+                const float sq = v * v;
+#pragma unroll
+                for (int co = 0; co < CT; ++co)
+                    nrm[co] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[co][jj], sq, nrm[co], 0, 0, 0);
+            }
+        }
+        ++sc;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float nv = nrm[ct][r];
+            y[ct][r] *= INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv);
+        }
+}
+
+// issue packed-gamma piece 0 into `buf`
+template <int CT, int NW>
+__device__ __forceinline__ void issue_gamma0(const LayerArgs &p, char *buf, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < (CT * 4 + NW - 1) / NW; ++i) {
+        const int j = wave + i * NW;
+        if (j < CT * 4) glds16((const char *)p.gp + j * 1024 + lane * 16, buf + j * 1024);
+    }
+}
+
+// ---- epilogue store of CT accumulator tiles ---------------------------------------------------
+// (oy, ox): this lane's output pixel; valid: inside the image.
+template <int CT>
+__device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
+                                            int h, bool valid) {
+    if (!valid) return;
+    if (p.outfmt == OUT_C8) {
+        float *out = (float *)p.out;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int plane = 4 * ct + g;
+                if (plane < p.out_planes) {
+                    f32x4 v = {acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
+                    float *dst = out + ((((size_t)n * p.out_planes + plane) * p.OH + oy) * p.OW + ox) * 8 + 4 * h;
+                    *(f32x4 *)dst = v;
+                }
+            }
+    } else if (p.outfmt == OUT_NCHW) {
+        float *out = (float *)p.out;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = 32 * ct + acc_row(r) + 4 * h;
+                if (c < p.cout) out[(((size_t)n * p.cout + c) * p.OH + oy) * p.OW + ox] = acc[ct][r];
+            }
+    } else {  // OUT_U8HWC: x*255 -> clip(0,255) -> truncating cast  (_autoencoders.py:576-580)
+        uint8_t *out = (uint8_t *)p.out;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = 32 * ct + acc_row(r) + 4 * h;
+                if (c < p.cout) {
+                    float v = acc[ct][r] * 255.0f;
+                    v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+                    out[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + c] = (uint8_t)v;
+                }
+            }
+    }
+}
+
+// =================================================================================================
+// Strided reflect convolution (+ bias) (+ GDN)
+//   block  = NW waves; wave w owns output rows 2w, 2w+1 of the tile, 16 columns each -> 32 pixels
+//   tile   = (2 NW) x 16 output pixels, all CT*32 output channels
+//   stage  = (8-channel chunk c, kernel row ky): KS taps x CT KiB of weights + TY halo rows
+// =================================================================================================
+template <int KS, int CT, int NW, bool GDN>
+__global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : 2) conv_s2_kernel(const LayerArgs p) {
+    constexpr int PAD = KS / 2;
+    constexpr int TX = 16, TY = 2 * NW;
+    constexpr int WH = 2 * TX + KS - 2;  // halo columns
+    constexpr int HALO_PIECES = TY * WH * 2;
+    constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;
+    constexpr int W_INSTR = KS * CT;
+    constexpr int W_BYTES = W_INSTR * 1024;
+    constexpr int G_BYTES = GDN ? CT * 4096 : 0;
+    constexpr int CONV_STAGE = W_BYTES + HALO_INSTR * 1024;
+    constexpr int STAGE_BYTES = CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES;
+    constexpr int MAXP = (HALO_INSTR + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n = bid / p.tiles_y;
+    const int oy0 = ty * TY, ox0 = tx * TX;
+
+    // per-lane halo pieces: piece = (row r, column x, half) -> LDS offset 16*piece
+    int hrow[MAXP], hxoff[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        int pc = (wave + i * NW) * 64 + lane;
+        pc = pc < HALO_PIECES ? pc : HALO_PIECES - 1;
+        const int r = pc / (2 * WH);
+        const int rem = pc - r * (2 * WH);
+        const int x = rem >> 1;
+        hrow[i] = 2 * (oy0 + r) - PAD;
+        hxoff[i] = reflect_idx(2 * ox0 - PAD + x, p.W) * 8 + (rem & 1) * 4;
+    }
+    const size_t plane_sz = (size_t)p.H * p.W * 8;
+    const float *in_n = p.in + (size_t)n * p.in_planes * plane_sz;
+
+    auto issue_stage = [&](int s, char *buf) {
+        const int c = s / KS, ky = s - c * KS;
+        const char *wsrc = (const char *)p.wp + (size_t)s * W_BYTES;
+#pragma unroll
+        for (int i = 0; i < (W_INSTR + NW - 1) / NW; ++i) {
+            const int j = wave + i * NW;
+            if (j < W_INSTR) glds16(wsrc + j * 1024 + lane * 16, buf + j * 1024);
+        }
+        const float *plane = in_n + (size_t)c * plane_sz;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int j = wave + i * NW;
+            if (j < HALO_INSTR) {
+                const int iy = reflect_idx(hrow[i] + ky, p.H);
+                glds16(plane + (size_t)iy * p.W * 8 + hxoff[i], buf + W_BYTES + j * 1024);
+            }
+        }
+    };
+
+    f32x16 acc[CT];
+    init_acc<CT>(acc, p.bias, h, 0.0f);
+
+    const int wrow = 2 * wave + (m >> 4);
+    const int b_off = W_BYTES + ((wrow * WH + 2 * (m & 15)) * 8 + 4 * h) * 4;
+    const int NS = p.cci * KS;
+    int sc = 0;
+
+    issue_stage(0, smem);
+    for (int s = 0; s < NS; ++s) {
+        wait_vm0();
+        __syncthreads();
+        char *cur = smem + (sc & 1) * STAGE_BYTES;
+        char *nxt = smem + ((sc + 1) & 1) * STAGE_BYTES;
+        if (s + 1 < NS) {
+            issue_stage(s + 1, nxt);
+        } else if (GDN) {
+            issue_gamma0<CT, NW>(p, nxt, wave, lane);
+        }
+        const char *wb = cur + lane * 16;
+        const char *hb = cur + b_off;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const f32x4 b = *(const f32x4 *)(hb + kx * 32);
+            f32x4 a[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) a[ct] = *(const f32x4 *)(wb + (kx * CT + ct) * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct][j], b[j], acc[ct], 0, 0, 0);
+        }
+        ++sc;
+    }
+
+    if constexpr (GDN) {
+        gdn_stages<CT, NW, false, STAGE_BYTES>(acc, p, smem, sc, wave, lane, [](char *) {});
+    }
+
+    const int oy = oy0 + wrow, ox = ox0 + (m & 15);
+    store_tiles<CT>(acc, p, n, oy, ox, h, oy < p.OH && ox < p.OW);
+}
+
+// =================================================================================================
+// Stride-2 transposed convolution (+ bias) (+ IGDN), sub-pixel (phase) decomposition:
+//   out[2i+py][2j+px] = sum_{d,dx} in[i-d][j-dx] . W[:, :, 2d+py+P, 2dx+px+P]      (P = KS/2)
+//   block  = NW waves; wave w owns INPUT row ty0+w, 32 input columns -> output rows 2i, 2i+1
+//   per py: two accumulator sets (px = 0, 1); stage = (chunk c, kernel row ky(py, d))
+// =================================================================================================
+template <int KS, int CT, int NW, bool IGDN>
+struct DeconvGeom {
+    static constexpr int P = KS / 2;
+    static constexpr int DLO = -((P + 1) / 2), DHI = (KS - 1 - P) / 2;  // range of dx over both px
+    static constexpr int WH = 32 + DHI - DLO;
+    static constexpr int HALO_PIECES = NW * WH * 2;
+    static constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;
+    static constexpr int W_INSTR = KS * CT;
+    static constexpr int W_BYTES = W_INSTR * 1024;
+    static constexpr int G_BYTES = IGDN ? CT * 4096 : 0;
+    static constexpr int CONV_STAGE = W_BYTES + HALO_INSTR * 1024;
+    static constexpr int STAGE_BYTES = CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES;
+    static constexpr int MAXP = (HALO_INSTR + NW - 1) / NW;
+    static constexpr int dmin(int py) { return -((py + P) / 2); }
+    static constexpr int nky(int py) { return (KS - 1 - py - P) / 2 - dmin(py) + 1; }
+};
+
+template <int KS, int CT, int NW, bool IGDN, int PY>
+__device__ __forceinline__ void deconv_issue(const LayerArgs &p, const float *in_n, size_t plane_sz, int s, char *buf,
+                                             const int *hrow, const int *hxoff, int wave, int lane) {
+    using G = DeconvGeom<KS, CT, NW, IGDN>;
+    constexpr int NKY = G::nky(PY);
+    const int c = s / NKY, d = G::dmin(PY) + (s - c * NKY);
+    const int ky = 2 * d + PY + G::P;
+    const char *wsrc = (const char *)p.wp + (size_t)(c * KS + ky) * G::W_BYTES;
+#pragma unroll
+    for (int i = 0; i < (G::W_INSTR + NW - 1) / NW; ++i) {
+        const int j = wave + i * NW;
+        if (j < G::W_INSTR) glds16(wsrc + j * 1024 + lane * 16, buf + j * 1024);
+    }
+    const float *plane = in_n + (size_t)c * plane_sz;
+#pragma unroll
+    for (int i = 0; i < G::MAXP; ++i) {
+        const int j = wave + i * NW;
+        if (j < G::HALO_INSTR) {
+            const int iy = hrow[i] - d;
+            const bool ok = iy >= 0 && iy < p.H && hxoff[i] >= 0;
+            const float *src = ok ? plane + (size_t)iy * p.W * 8 + hxoff[i] : p.zero;
+            glds16(src, buf + G::W_BYTES + j * 1024);
+        }
+    }
+}
+
+template <int KS, int CT, int NW, bool IGDN, int PY>
+__device__ __forceinline__ void deconv_phase(const LayerArgs &p, const float *in_n, size_t plane_sz, char *smem,
+                                             int &sc, const int *hrow, const int *hxoff, int wave, int lane,
+                                             int b_off, int n, int iy, int ix, bool valid) {
+    using G = DeconvGeom<KS, CT, NW, IGDN>;
+    constexpr int P = G::P;
+    constexpr int STAGE_BYTES = G::STAGE_BYTES;
+    const int h = lane >> 5;
+    const int NS = p.cci * G::nky(PY);
+    f32x16 acc0[CT], acc1[CT];
+    init_acc<CT>(acc0, p.bias, h, 0.0f);
+    init_acc<CT>(acc1, p.bias, h, 0.0f);
+
+    for (int s = 0; s < NS; ++s) {
+        wait_vm0();
+        __syncthreads();
+        char *cur = smem + (sc & 1) * STAGE_BYTES;
+        char *nxt = smem + ((sc + 1) & 1) * STAGE_BYTES;
+        if (s + 1 < NS) {
+            deconv_issue<KS, CT, NW, IGDN, PY>(p, in_n, plane_sz, s + 1, nxt, hrow, hxoff, wave, lane);
+        } else if (IGDN) {
+            issue_gamma0<CT, NW>(p, nxt, wave, lane);
+        } else if (PY == 0) {
+            deconv_issue<KS, CT, NW, IGDN, 1>(p, in_n, plane_sz, 0, nxt, hrow, hxoff, wave, lane);
+        }
+        const char *wb = cur + lane * 16;
+        const char *hb = cur + b_off;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            // kx = 2 dx + px + P  ->  px = parity(kx - P), dx = (kx - P - px) / 2
+            const int px = (kx + P) & 1;
+            const int dx = (kx - P - px) / 2;
+            const f32x4 b = *(const f32x4 *)(hb - dx * 32);
+            f32x4 a[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) a[ct] = *(const f32x4 *)(wb + (kx * CT + ct) * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (px == 0)
+                        acc0[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct][j], b[j], acc0[ct], 0, 0, 0);
+                    else
+                        acc1[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct][j], b[j], acc1[ct], 0, 0, 0);
+                }
+        }
+        ++sc;
+    }
+
+    if constexpr (IGDN) {
+        gdn_stages<CT, NW, true, STAGE_BYTES>(acc0, p, smem, sc, wave, lane,
+                                              [&](char *nxt) { issue_gamma0<CT, NW>(p, nxt, wave, lane); });
+        store_tiles<CT>(acc0, p, n, 2 * iy + PY, 2 * ix, h, valid);
+        gdn_stages<CT, NW, true, STAGE_BYTES>(acc1, p, smem, sc, wave, lane, [&](char *nxt) {
+            if (PY == 0) deconv_issue<KS, CT, NW, IGDN, 1>(p, in_n, plane_sz, 0, nxt, hrow, hxoff, wave, lane);
+        });
+        store_tiles<CT>(acc1, p, n, 2 * iy + PY, 2 * ix + 1, h, valid);
+    } else {
+        store_tiles<CT>(acc0, p, n, 2 * iy + PY, 2 * ix, h, valid);
+        store_tiles<CT>(acc1, p, n, 2 * iy + PY, 2 * ix + 1, h, valid);
+    }
+}
+
+template <int KS, int CT, int NW, bool IGDN>
+__global__ void __launch_bounds__(NW * 64, CT >= 6 ? 1 : 2) deconv_s2_kernel(const LayerArgs p) {
+    using G = DeconvGeom<KS, CT, NW, IGDN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n = bid / p.tiles_y;
+    const int iy0 = ty * NW, ix0 = tx * 32;
+
+    int hrow[G::MAXP], hxoff[G::MAXP];  // hxoff < 0: column outside the image
+#pragma unroll
+    for (int i = 0; i < G::MAXP; ++i) {
+        int pc = (wave + i * NW) * 64 + lane;
+        pc = pc < G::HALO_PIECES ? pc : G::HALO_PIECES - 1;
+        const int r = pc / (2 * G::WH);
+        const int rem = pc - r * (2 * G::WH);
+        const int ix = ix0 + (rem >> 1) - G::DHI;
+        hrow[i] = iy0 + r;
+        hxoff[i] = (ix >= 0 && ix < p.W) ? ix * 8 + (rem & 1) * 4 : -1;
+    }
+    const size_t plane_sz = (size_t)p.H * p.W * 8;
+    const float *in_n = p.in + (size_t)n * p.in_planes * plane_sz;
+
+    const int b_off = G::W_BYTES + ((wave * G::WH + m + G::DHI) * 8 + 4 * h) * 4;
+    const int iy = iy0 + wave, ix = ix0 + m;
+    const bool valid = iy < p.H && ix < p.W;
+    int sc = 0;
+
+    deconv_issue<KS, CT, NW, IGDN, 0>(p, in_n, plane_sz, 0, smem, hrow, hxoff, wave, lane);
+    deconv_phase<KS, CT, NW, IGDN, 0>(p, in_n, plane_sz, smem, sc, hrow, hxoff, wave, lane, b_off, n, iy, ix, valid);
+    deconv_phase<KS, CT, NW, IGDN, 1>(p, in_n, plane_sz, smem, sc, hrow, hxoff, wave, lane, b_off, n, iy, ix, valid);
+}
+
+// =================================================================================================
+// Stand-alone GDN / IGDN on a C8 tensor (nn.Module surface for compressai.layers.GDN)
+//   block = NW waves, each wave 32 consecutive pixels of the flattened H*W plane.
+// =================================================================================================
+template <int CT, int NW, bool INVERSE>
+__global__ void __launch_bounds__(NW * 64, CT >= 6 ? 1 : 2) gdn_c8_kernel(const LayerArgs p) {
+    constexpr int STAGE_BYTES = CT * 4096;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    const int hw = p.H * p.W;
+    const int blocks_per_img = (hw + NW * 32 - 1) / (NW * 32);
+    const int n = blockIdx.x / blocks_per_img;
+    const int pix = (blockIdx.x - n * blocks_per_img) * (NW * 32) + wave * 32 + m;
+    const bool valid = pix < hw;
+    int sc = 0;
+    issue_gamma0<CT, NW>(p, smem, wave, lane);
+    f32x16 y[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int plane = 4 * ct + g;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (valid && plane < p.in_planes)
+                v = *(const f32x4 *)(p.in + (((size_t)n * p.in_planes + plane) * hw + pix) * 8 + 4 * h);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[ct][4 * g + k] = v[k];
+        }
+    gdn_stages<CT, NW, INVERSE, STAGE_BYTES>(y, p, smem, sc, wave, lane, [](char *) {});
+    const int oy = pix / p.W, ox = pix - oy * p.W;
+    store_tiles<CT>(y, p, n, oy, ox, h, valid);
+}
+
+// ---- layout conversion / quantiser kernels (HBM-bound, one element group per thread) ------------
+
+// (n,h,w,c) uint8 -> C8 float / 255   (_autoencoders.py:542-545; true division, as torch does)
+__global__ void u8hwc_to_c8_kernel(const uint8_t *in, float *out, int N, int H, int W, int C, int planes) {
+    const size_t total = (size_t)N * planes * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i % ((size_t)H * W);
+        const size_t np = i / ((size_t)H * W);
+        const int plane = (int)(np % planes);
+        const size_t n = np / planes;
+        const uint8_t *src = in + (n * H * W + pix) * C;
+        f32x4 lo, hi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c0 = plane * 8 + k, c1 = c0 + 4;
+            lo[k] = c0 < C ? (float)src[c0] / 255.0f : 0.0f;
+            hi[k] = c1 < C ? (float)src[c1] / 255.0f : 0.0f;
+        }
+        float *dst = out + i * 8;
+        *(f32x4 *)dst = lo;
+        *(f32x4 *)(dst + 4) = hi;
+    }
+}
+
+__global__ void nchw_to_c8_kernel(const float *in, float *out, int N, int C, int HW, int planes) {
+    const size_t total = (size_t)N * planes * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i % HW;
+        const size_t np = i / HW;
+        const int plane = (int)(np % planes);
+        const size_t n = np / planes;
+        f32x4 lo, hi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c0 = plane * 8 + k, c1 = c0 + 4;
+            lo[k] = c0 < C ? in[(n * C + c0) * HW + pix] : 0.0f;
+            hi[k] = c1 < C ? in[(n * C + c1) * HW + pix] : 0.0f;
+        }
+        float *dst = out + i * 8;
+        *(f32x4 *)dst = lo;
+        *(f32x4 *)(dst + 4) = hi;
+    }
+}
+
+__global__ void c8_to_nchw_kernel(const float *in, float *out, int N, int C, int HW, int planes) {
+    const size_t total = (size_t)N * C * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i % HW;
+        const size_t nc = i / HW;
+        const int c = (int)(nc % C);
+        const size_t n = nc / C;
+        out[i] = in[((n * planes + (c >> 3)) * HW + pix) * 8 + (c & 7)];
+    }
+}
+
+// symbols = int(round_half_even(y - median_c))     (EntropyBottleneck.compress, Appendix A.3)
+__global__ void quantize_kernel(const float *y, const float *medians, int32_t *sym, int C, int HW, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW) % C);
+        sym[i] = (int32_t)rintf(y[i] - medians[c]);
+    }
+}
+
+// y_hat = float(symbols) + median_c                (EntropyModel.dequantize)
+__global__ void dequantize_kernel(const int32_t *sym, const float *medians, float *y, int C, int HW, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW) % C);
+        y[i] = (float)sym[i] + medians[c];
+    }
+}
+
+}  // namespace cae

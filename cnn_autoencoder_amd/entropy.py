@@ -1,0 +1,293 @@
+"""Factorized entropy bottleneck: host-side mirror of ``compressai.entropy_models.EntropyBottleneck``.
+
+The reference builds this class at ``src/models/tasks/_autoencoders.py:476-477`` and calls
+``update(force=True)`` (:502), ``compress`` (:549-551), ``decompress`` (:568-571), ``loss()``
+(``criteria/_lossutils.py:70``) and ``__call__`` (``_taskutils.py:97``) on it.  Same constructor,
+parameter / buffer names and return conventions here; the quantiser runs as a HIP kernel and the
+range coder / CDF quantiser are the C++ entry points of libcae_hip.so (no compressai, no CPU
+fallback for the coding path).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+class _LowerBoundFn(torch.autograd.Function):
+    """max(x, bound) with the compressai gradient rule (pass where x >= bound or grad < 0)."""
+
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x, bound)
+        return torch.max(x, bound)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bound = ctx.saved_tensors
+        pass_through = (x >= bound) | (g < 0)
+        return pass_through.to(g.dtype) * g, None
+
+
+class LowerBound(nn.Module):
+    def __init__(self, bound: float):
+        super().__init__()
+        self.register_buffer('bound', torch.Tensor([float(bound)]))
+
+    def forward(self, x):
+        return _LowerBoundFn.apply(x, self.bound)
+
+
+def pmf_to_quantized_cdf(pmf: torch.Tensor, precision: int = 16) -> torch.Tensor:
+    """compressai._CXX.pmf_to_quantized_cdf through the C ABI (cae_pmf_to_quantized_cdf)."""
+    p = np.ascontiguousarray(pmf.detach().cpu().numpy(), dtype=np.float32)
+    out = np.empty(p.shape[0] + 1, dtype=np.uint32)
+    _lib.check(_lib.lib().cae_pmf_to_quantized_cdf(p.ctypes.data, p.shape[0], precision, out.ctypes.data))
+    return torch.from_numpy(out.astype(np.int32))
+
+
+def _logits_cumulative(params, n_filters: int, inputs: torch.Tensor) -> torch.Tensor:
+    """Cumulative-logit network of the factorized prior."""
+    logits = inputs
+    for i in range(n_filters + 1):
+        logits = torch.matmul(F.softplus(params[f'_matrix{i:d}']), logits)
+        logits = logits + params[f'_bias{i:d}']
+        if i < n_filters:
+            logits = logits + torch.tanh(params[f'_factor{i:d}']) * torch.tanh(logits)
+    return logits
+
+
+def _likelihood(params, n_filters: int, inputs: torch.Tensor):
+    lower = _logits_cumulative(params, n_filters, inputs - 0.5)
+    upper = _logits_cumulative(params, n_filters, inputs + 0.5)
+    sign = -torch.sign(lower + upper).detach()
+    likelihood = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+    return likelihood, lower, upper
+
+
+class EntropyBottleneck(nn.Module):
+    def __init__(self, channels: int, *args, tail_mass: float = 1e-9, init_scale: float = 10,
+                 filters: Sequence[int] = (3, 3, 3, 3), likelihood_bound: float = 1e-9,
+                 entropy_coder_precision: int = 16, **kwargs):
+        super().__init__()
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+        self.entropy_coder_precision = int(entropy_coder_precision)
+        self.use_likelihood_bound = likelihood_bound > 0
+        if self.use_likelihood_bound:
+            self.likelihood_lower_bound = LowerBound(likelihood_bound)
+
+        self.register_buffer('_offset', torch.IntTensor())
+        self.register_buffer('_quantized_cdf', torch.IntTensor())
+        self.register_buffer('_cdf_length', torch.IntTensor())
+
+        filters_ = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.filters) + 1))
+        for i in range(len(self.filters) + 1):
+            init = np.log(np.expm1(1 / scale / filters_[i + 1]))
+            matrix = torch.Tensor(channels, filters_[i + 1], filters_[i])
+            matrix.data.fill_(init)
+            self.register_parameter(f'_matrix{i:d}', nn.Parameter(matrix))
+            bias = torch.Tensor(channels, filters_[i + 1], 1)
+            nn.init.uniform_(bias, -0.5, 0.5)
+            self.register_parameter(f'_bias{i:d}', nn.Parameter(bias))
+            if i < len(self.filters):
+                factor = torch.Tensor(channels, filters_[i + 1], 1)
+                nn.init.zeros_(factor)
+                self.register_parameter(f'_factor{i:d}', nn.Parameter(factor))
+
+        self.quantiles = nn.Parameter(torch.Tensor(channels, 1, 3))
+        init = torch.Tensor([-self.init_scale, 0, self.init_scale])
+        self.quantiles.data = init.repeat(self.quantiles.size(0), 1, 1)
+        target = np.log(2 / self.tail_mass - 1)
+        self.register_buffer('target', torch.Tensor([-target, 0, target]))
+
+        self._handle: Optional[_lib.Handle] = None
+        self._tables_version = -1
+
+    # ---- state dict: integer buffers change size with the model --------------------------------
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for name in ('_offset', '_quantized_cdf', '_cdf_length'):
+            key = prefix + name
+            if key in state_dict:
+                setattr(self, name, torch.empty_like(state_dict[key], dtype=torch.int32,
+                                                     device=getattr(self, name).device))
+        self._tables_version = -1
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    # ---- density model (torch ops; training / rate estimate only) ------------------------------
+    def _get_medians(self) -> torch.Tensor:
+        return self.quantiles[:, :, 1:2]
+
+    def _params(self, stop_gradient: bool = False, cpu: bool = False):
+        out = {}
+        for k, v in self.named_parameters(recurse=False):
+            if stop_gradient or cpu:
+                v = v.detach()
+            out[k] = v.cpu().float() if cpu else v
+        return out
+
+    def _likelihood(self, inputs: torch.Tensor, stop_gradient: bool = False):
+        return _likelihood(self._params(stop_gradient), len(self.filters), inputs)
+
+    def forward(self, x: torch.Tensor, training: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if training is None:
+            training = self.training
+        perm = list(range(x.dim()))
+        perm[0], perm[1] = 1, 0
+        x = x.permute(*perm).contiguous()
+        shape = x.size()
+        values = x.reshape(x.size(0), 1, -1)
+        if training:
+            outputs = values + torch.empty_like(values).uniform_(-0.5, 0.5)
+        else:
+            medians = self._get_medians()
+            outputs = torch.round(values - medians) + medians
+        likelihood, _, _ = self._likelihood(outputs)
+        if self.use_likelihood_bound:
+            likelihood = self.likelihood_lower_bound(likelihood)
+        outputs = outputs.reshape(shape).permute(*perm).contiguous()
+        likelihood = likelihood.reshape(shape).permute(*perm).contiguous()
+        return outputs, likelihood
+
+    def loss(self) -> torch.Tensor:
+        logits = _logits_cumulative(self._params(stop_gradient=True), len(self.filters), self.quantiles)
+        return torch.abs(logits - self.target).sum()
+
+    @torch.no_grad()
+    def fit_quantiles(self, iters: int = 60):
+        """Move ``quantiles`` to the fixed point of ``loss()`` (logits(q) = target) by bisection.
+
+        This is what the reference's ``_aux`` optimiser converges to during training
+        (train_cae_ms.py:592-596); used to give synthetic, untrained models a realistic CDF support.
+        """
+        q = self.quantiles.detach().clone().cpu()
+        params = self._params(cpu=True)
+
+        def logits(v):
+            return _logits_cumulative(params, len(self.filters), v)
+
+        target = self.target.detach().cpu().view(1, 1, 3)
+        lo = torch.full_like(q, -1e4)
+        hi = torch.full_like(q, 1e4)
+        for _ in range(iters):
+            mid = 0.5 * (lo + hi)
+            above = logits(mid) > target
+            hi = torch.where(above, mid, hi)
+            lo = torch.where(above, lo, mid)
+        self.quantiles.data.copy_((0.5 * (lo + hi)).to(self.quantiles.device))
+        self._tables_version = -1
+
+    # ---- integer tables ----------------------------------------------------------------------
+    @torch.no_grad()
+    def update(self, force: bool = False) -> bool:
+        if self._offset.numel() > 0 and not force:
+            return False
+        dev = self.quantiles.device
+        params = self._params(cpu=True)  # CDFs are built on the host with torch-CPU fp32 ops
+        q = params['quantiles']
+        medians = q[:, 0, 1]
+        minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
+        maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
+        offset = -minima
+        pmf_start = medians - minima
+        pmf_length = maxima + minima + 1
+        max_length = int(pmf_length.max().item())
+        samples = torch.arange(max_length)
+        samples = samples[None, :] + pmf_start[:, None, None]
+        pmf, lower, upper = _likelihood(params, len(self.filters), samples)
+        pmf = pmf[:, 0, :]
+        tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+        cdf = torch.zeros((len(pmf_length), max_length + 2), dtype=torch.int32)
+        for i, p in enumerate(pmf):
+            prob = torch.cat((p[:pmf_length[i]], tail_mass[i]), dim=0)
+            c = pmf_to_quantized_cdf(prob, self.entropy_coder_precision)
+            cdf[i, :c.size(0)] = c
+        self._offset = offset.to(dev)
+        self._quantized_cdf = cdf.to(dev)
+        self._cdf_length = (pmf_length + 2).int().to(dev)
+        self._tables_version = -1
+        return True
+
+    # ---- coding (hot path) ---------------------------------------------------------------------
+    def _sync_handle(self) -> _lib.Handle:
+        if self._quantized_cdf.numel() == 0:
+            raise ValueError('Uninitialized CDFs. Run update() first')
+        ver = (self._quantized_cdf._version, self.quantiles._version, self._quantized_cdf.data_ptr())
+        if self._handle is None:
+            self._handle = _lib.Handle(1, 1, self.channels, 1, 3)
+        if self._tables_version != ver:
+            cdf = np.ascontiguousarray(self._quantized_cdf.detach().cpu().numpy(), dtype=np.int32)
+            if cdf.ndim != 2 or cdf.shape[0] != self.channels:
+                raise ValueError(f'Invalid CDF size {tuple(cdf.shape)}')
+            lens = np.ascontiguousarray(self._cdf_length.detach().cpu().numpy().reshape(-1), dtype=np.int32)
+            offs = np.ascontiguousarray(self._offset.detach().cpu().numpy().reshape(-1), dtype=np.int32)
+            med = np.ascontiguousarray(self._get_medians().detach().cpu().numpy().reshape(-1), dtype=np.float32)
+            _lib.check(_lib.lib().cae_model_set_entropy(self._handle.ptr, self.channels, cdf.shape[1],
+                                                        cdf.ctypes.data, lens.ctypes.data, offs.ctypes.data,
+                                                        med.ctypes.data))
+            self._tables_version = ver
+        return self._handle
+
+    @torch.no_grad()
+    def quantize_symbols(self, x: torch.Tensor) -> torch.Tensor:
+        """(B,C,...) float -> int32 symbols on the GPU (HIP quantiser kernel)."""
+        dev = _lib.require_gpu()
+        h = self._sync_handle()
+        if x.dim() < 3 or x.size(1) != self.channels:
+            raise ValueError(f'Invalid input shape {tuple(x.shape)} for {self.channels} channels')
+        x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        hw = int(np.prod(x.shape[2:]))
+        sym = torch.empty(x.shape, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().cae_quantize(h.ptr, x.data_ptr(), x.size(0), hw, sym.data_ptr(), _lib.stream_ptr()))
+        return sym
+
+    def encode_symbols(self, sym_host: np.ndarray, threads: int = 0) -> List[bytes]:
+        """(B,C,hw) int32 host symbols -> one rANS byte string per batch item."""
+        h = self._sync_handle()
+        sym_host = np.ascontiguousarray(sym_host, dtype=np.int32)
+        n = sym_host.shape[0]
+        hw = int(np.prod(sym_host.shape[2:])) if sym_host.ndim > 2 else 1
+        bufs = (ctypes.c_void_p * n)()
+        lens = (ctypes.c_size_t * n)()
+        _lib.check(_lib.lib().cae_rans_encode_batch(h.ptr, sym_host.ctypes.data, n, hw, bufs, lens, threads))
+        out = []
+        for i in range(n):
+            out.append(ctypes.string_at(bufs[i], lens[i]))
+            _lib.lib().cae_free(bufs[i])
+        return out
+
+    def decode_symbols(self, strings: Sequence[bytes], hw: int, threads: int = 0) -> np.ndarray:
+        h = self._sync_handle()
+        n = len(strings)
+        keep = [bytes(s) for s in strings]
+        bufs = (ctypes.c_char_p * n)(*keep)
+        lens = (ctypes.c_size_t * n)(*[len(s) for s in keep])
+        sym = np.empty((n, self.channels, hw), dtype=np.int32)
+        _lib.check(_lib.lib().cae_rans_decode_batch(h.ptr, bufs, lens, n, hw, sym.ctypes.data, threads))
+        return sym
+
+    @torch.no_grad()
+    def compress(self, x: torch.Tensor) -> List[bytes]:
+        sym = self.quantize_symbols(x)
+        return self.encode_symbols(sym.reshape(sym.size(0), sym.size(1), -1).cpu().numpy())
+
+    @torch.no_grad()
+    def decompress(self, strings: Sequence[bytes], size) -> torch.Tensor:
+        dev = _lib.require_gpu()
+        h = self._sync_handle()
+        size = tuple(int(s) for s in size)
+        hw = int(np.prod(size))
+        sym = torch.from_numpy(self.decode_symbols(strings, hw)).to(dev)
+        out = torch.empty((len(strings), self.channels) + size, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().cae_dequantize(h.ptr, sym.data_ptr(), len(strings), hw, out.data_ptr(),
+                                             _lib.stream_ptr()))
+        return out

@@ -1,0 +1,315 @@
+"""Analysis / synthesis stacks with the reference's ``nn.Module`` call surface.
+
+Mirrors ``src/models/tasks/_autoencoders.py`` of the reference:
+``DownsamplingUnit`` :53-101, ``UpsamplingUnit`` :177-227, ``Analyzer`` :307-361,
+``Synthesizer`` :364-455, ``initialize_weights`` :37-42 and ``compressai.layers.GDN``
+(call site :29-30).  Same constructor arguments, same state-dict keys
+(``analysis_track.{i}.model.{0|1}.{weight|bias|beta|gamma}``), same return values -- but
+``forward`` runs the whole track as fused HIP kernels through libcae_hip.so.  The parameters
+live in ordinary ``nn.Parameter`` tensors (so checkpoints, ``.cuda()``, optimisers and
+``load_state_dict`` keep working) and are re-packed into the device-side MFMA layout whenever
+they change.  There is no CPU execution path.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .entropy import LowerBound
+
+REPARAM_OFFSET = 2.0 ** -18
+
+
+class NonNegativeParametrizer(nn.Module):
+    """compressai.ops.parametrizers.NonNegativeParametrizer."""
+
+    def __init__(self, minimum: float = 0, reparam_offset: float = REPARAM_OFFSET):
+        super().__init__()
+        self.minimum = float(minimum)
+        self.reparam_offset = float(reparam_offset)
+        pedestal = self.reparam_offset ** 2
+        self.register_buffer('pedestal', torch.Tensor([pedestal]))
+        bound = (self.minimum + self.reparam_offset ** 2) ** 0.5
+        self.lower_bound = LowerBound(bound)
+
+    def init(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.sqrt(torch.max(x + self.pedestal, self.pedestal))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        out = self.lower_bound(x)
+        return out ** 2 - self.pedestal
+
+
+class GDN(nn.Module):
+    """Parameter holder + stand-alone forward for compressai.layers.GDN."""
+
+    def __init__(self, in_channels: int, inverse: bool = False, beta_min: float = 1e-6, gamma_init: float = 0.1):
+        super().__init__()
+        self.inverse = bool(inverse)
+        self.in_channels = int(in_channels)
+        self.beta_reparam = NonNegativeParametrizer(minimum=float(beta_min))
+        self.beta = nn.Parameter(self.beta_reparam.init(torch.ones(in_channels)))
+        self.gamma_reparam = NonNegativeParametrizer()
+        self.gamma = nn.Parameter(self.gamma_reparam.init(float(gamma_init) * torch.eye(in_channels)))
+        self._owner = None  # (track module, layer index), set by the owning Analyzer / Synthesizer
+
+    @torch.no_grad()
+    def effective(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.beta_reparam(self.beta), self.gamma_reparam(self.gamma)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._owner is None:
+            raise RuntimeError('GDN layer is not attached to an Analyzer/Synthesizer')
+        track, index = self._owner
+        return track()._gdn_forward(index, x)
+
+
+class _ConvParams(nn.Module):
+    """Weight/bias holder standing where the reference has nn.Conv2d / nn.ConvTranspose2d."""
+
+    transposed = False
+
+    def __init__(self, channels_in: int, channels_out: int, kernel_size: int, bias: bool):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = channels_in, channels_out, kernel_size
+        shape = ((channels_in, channels_out) if self.transposed else (channels_out, channels_in))
+        self.weight = nn.Parameter(torch.empty(*shape, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(channels_out)) if bias else None
+        # default nn.Conv2d init first (keeps the RNG stream aligned with the reference ctor) ...
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.weight.size(1) * kernel_size * kernel_size
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        raise NotImplementedError('layers run fused: call the owning Analyzer / Synthesizer')
+
+
+class StridedReflectConv2d(_ConvParams):
+    transposed = False
+
+
+class StridedConvTranspose2d(_ConvParams):
+    transposed = True
+
+
+def initialize_weights(m):
+    """reference initialize_weights (_autoencoders.py:37-42)."""
+    if isinstance(m, _ConvParams):
+        nn.init.xavier_uniform_(m.weight.data, gain=math.sqrt(2 / 1.01))
+        if m.bias is not None:
+            nn.init.constant_(m.bias.data, 0.01)
+
+
+def _check_variant(kernel_size, groups, batch_norm, dropout, use_residual, act_layer_type, channels_expansion):
+    if act_layer_type not in (None, 'GDN'):
+        raise NotImplementedError(f"act_layer_type={act_layer_type!r}: only None and 'GDN' run on the HIP path "
+                                  '(LeakyReLU/ReLU units are a later scope row, SURVEY §8f.2)')
+    if groups or batch_norm or use_residual or channels_expansion != 1:
+        raise NotImplementedError('groups / batch_norm / use_residual / channels_expansion variants are not built yet')
+    if kernel_size not in (3, 5):
+        raise NotImplementedError('kernel_size must be 3 or 5')
+    del dropout  # Dropout2d is the identity in eval mode
+
+
+class DownsamplingUnit(nn.Module):
+    def __init__(self, channels_in, channels_out, kernel_size=3, groups=False, batch_norm=False, dropout=0.0,
+                 bias=False, act_layer_type=None):
+        super().__init__()
+        model = [StridedReflectConv2d(channels_in, channels_out, kernel_size, bias)]
+        if act_layer_type == 'GDN':
+            model.append(GDN(channels_out, inverse=False))
+        self.model = nn.Sequential(*model)
+
+
+class UpsamplingUnit(nn.Module):
+    def __init__(self, channels_in, channels_out, kernel_size=3, groups=False, batch_norm=False, dropout=0.0,
+                 bias=True, act_layer_type=None):
+        super().__init__()
+        model = [StridedConvTranspose2d(channels_in, channels_out, kernel_size, bias)]
+        if act_layer_type == 'GDN':
+            model.append(GDN(channels_out, inverse=True))
+        self.model = nn.Sequential(*model)
+
+
+class _Track(nn.Module):
+    """Shared device plumbing of Analyzer / Synthesizer."""
+
+    _track_id = _lib.CAE_ANALYSIS
+    _track_attr = 'analysis_track'
+
+    def _setup(self, channels_org, channels_net, channels_bn, compression_level, kernel_size):
+        self._dims = (int(channels_org), int(channels_net), int(channels_bn), int(compression_level),
+                      int(kernel_size))
+        self._handle: Optional[_lib.Handle] = None
+        self._versions = None
+        import weakref
+        ref = weakref.ref(self)
+        for i, unit in enumerate(getattr(self, self._track_attr)):
+            for mod in unit.model:
+                if isinstance(mod, GDN):
+                    mod._owner = (ref, i)
+
+    def _units(self):
+        return list(getattr(self, self._track_attr))
+
+    def _param_versions(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _sync(self) -> _lib.Handle:
+        _lib.require_gpu()
+        if self._handle is None:
+            self._handle = _lib.Handle(*self._dims)
+        ver = self._param_versions()
+        if ver != self._versions:
+            L = _lib.lib()
+            with torch.no_grad():
+                for i, unit in enumerate(self._units()):
+                    conv = unit.model[0]
+                    w = np.ascontiguousarray(conv.weight.detach().float().cpu().numpy())
+                    b = None if conv.bias is None else np.ascontiguousarray(conv.bias.detach().float().cpu().numpy())
+                    beta = gamma = None
+                    if len(unit.model) > 1:
+                        be, ga = unit.model[1].effective()
+                        beta = np.ascontiguousarray(be.float().cpu().numpy())
+                        gamma = np.ascontiguousarray(ga.float().cpu().numpy())
+                    _lib.check(L.cae_model_set_layer(
+                        self._handle.ptr, self._track_id, i, conv.in_channels, conv.out_channels,
+                        w.ctypes.data, None if b is None else b.ctypes.data,
+                        None if beta is None else beta.ctypes.data, None if gamma is None else gamma.ctypes.data))
+            self._versions = ver
+        return self._handle
+
+    def _gdn_forward(self, index: int, x: torch.Tensor) -> torch.Tensor:
+        dev = _lib.require_gpu()
+        h = self._sync()
+        x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if x.dim() != 4:
+            raise ValueError(f'expected a 4-D (B,C,H,W) tensor, got {tuple(x.shape)}')
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().cae_gdn_forward(h.ptr, self._track_id, index, x.data_ptr(), x.size(0), x.size(2),
+                                              x.size(3), y.data_ptr(), _lib.stream_ptr()))
+        return y
+
+
+class Analyzer(_Track):
+    def __init__(self, channels_org=3, channels_net=8, channels_bn=16, compression_level=3, channels_expansion=1,
+                 kernel_size=3, groups=False, batch_norm=False, dropout=0.0, bias=False, use_residual=False,
+                 act_layer_type=None, **kwargs):
+        super().__init__()
+        _check_variant(kernel_size, groups, batch_norm, dropout, use_residual, act_layer_type, channels_expansion)
+        if compression_level < 1:
+            raise NotImplementedError('compression_level must be >= 1')
+        down_track = []
+        prev, curr = channels_org, channels_net
+        for _ in range(compression_level - 1):
+            down_track.append(DownsamplingUnit(prev, curr, kernel_size, groups, batch_norm, dropout, bias,
+                                               act_layer_type))
+            prev = curr
+        down_track.append(DownsamplingUnit(prev, channels_bn, kernel_size, groups, batch_norm, dropout, bias, None))
+        self.analysis_track = nn.Sequential(*down_track)
+        self.apply(initialize_weights)
+        self._setup(channels_org, channels_net, channels_bn, compression_level, kernel_size)
+
+    def latent_size(self, h: int, w: int) -> Tuple[int, int]:
+        for _ in range(self._dims[3]):
+            h, w = (h + 1) // 2, (w + 1) // 2
+        return h, w
+
+    def _run(self, ptr: int, fmt: int, n: int, h: int, w: int) -> torch.Tensor:
+        dev = _lib.require_gpu()
+        hd = self._sync()
+        lh, lw = self.latent_size(h, w)
+        y = torch.empty((n, self._dims[2], lh, lw), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().cae_analysis(hd.ptr, ptr, fmt, n, h, w, y.data_ptr(), _lib.stream_ptr()))
+        return y
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x (B,C,H,W) float in [0,1] -> y (B,channels_bn,ceil(H/2^L),ceil(W/2^L))."""
+        dev = _lib.require_gpu()
+        if x.dim() != 4 or x.size(1) != self._dims[0]:
+            raise ValueError(f'expected (B,{self._dims[0]},H,W), got {tuple(x.shape)}')
+        x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        return self._run(x.data_ptr(), _lib.FMT_F32_NCHW, x.size(0), x.size(2), x.size(3))
+
+    def forward_u8(self, tiles: torch.Tensor) -> torch.Tensor:
+        """tiles (B,H,W,C) uint8 on the GPU -> latents; fuses the /255 of codec.encode."""
+        dev = _lib.require_gpu()
+        if tiles.dim() != 4 or tiles.size(3) != self._dims[0] or tiles.dtype != torch.uint8:
+            raise ValueError(f'expected uint8 (B,H,W,{self._dims[0]}), got {tiles.dtype} {tuple(tiles.shape)}')
+        tiles = tiles.to(dev).contiguous()
+        return self._run(tiles.data_ptr(), _lib.FMT_U8_HWC, tiles.size(0), tiles.size(1), tiles.size(2))
+
+
+class NoneColorLayer(nn.Module):
+    def forward(self, *args, **kwargs):
+        return None
+
+
+class Synthesizer(_Track):
+    _track_id = _lib.CAE_SYNTHESIS
+    _track_attr = 'synthesis_track'
+
+    def __init__(self, channels_org=3, channels_net=8, channels_bn=16, compression_level=3, channels_expansion=1,
+                 kernel_size=3, groups=False, batch_norm=False, dropout=0.0, bias=False, use_residual=False,
+                 act_layer_type=None, multiscale_analysis=False, **kwargs):
+        super().__init__()
+        _check_variant(kernel_size, groups, batch_norm, dropout, use_residual, act_layer_type, channels_expansion)
+        if multiscale_analysis:
+            raise NotImplementedError('multiscale_analysis colour layers are not built yet')
+        if compression_level < 1:
+            raise NotImplementedError('compression_level must be >= 1')
+        up_track = []
+        prev, curr = channels_bn, channels_net
+        for _ in range(compression_level - 1):
+            up_track.append(UpsamplingUnit(prev, curr, kernel_size, groups, batch_norm, dropout, bias, act_layer_type))
+            prev = curr
+        up_track.append(UpsamplingUnit(prev, channels_org, kernel_size, groups, batch_norm, dropout, bias, None))
+        self.synthesis_track = nn.Sequential(*up_track)
+        color_layers = [nn.Sequential(NoneColorLayer()) for _ in range(compression_level - 1)]
+        color_layers += [nn.Identity()]
+        self.color_layers = nn.ModuleList(color_layers)
+        self.rec_level = compression_level
+        self.apply(initialize_weights)
+        self._setup(channels_org, channels_net, channels_bn, compression_level, kernel_size)
+
+    def _run(self, x: torch.Tensor, fmt: int, bridges: bool):
+        dev = _lib.require_gpu()
+        hd = self._sync()
+        if x.dim() != 4 or x.size(1) != self._dims[2]:
+            raise ValueError(f'expected (B,{self._dims[2]},h,w), got {tuple(x.shape)}')
+        x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        n, _, lh, lw = x.shape
+        L = self._dims[3]
+        H, W = lh * 2 ** L, lw * 2 ** L
+        if fmt == _lib.FMT_U8_HWC:
+            out = torch.empty((n, H, W, self._dims[0]), dtype=torch.uint8, device=dev)
+        else:
+            out = torch.empty((n, self._dims[0], H, W), dtype=torch.float32, device=dev)
+        brg: List[torch.Tensor] = []
+        brg_ptr = None
+        if bridges and L > 1:
+            brg = [torch.empty((n, self._dims[1], lh * 2 ** (i + 1), lw * 2 ** (i + 1)), dtype=torch.float32,
+                               device=dev) for i in range(L - 1)]
+            brg_ptr = (ctypes.c_void_p * (L - 1))(*[b.data_ptr() for b in brg])
+        _lib.check(_lib.lib().cae_synthesis(hd.ptr, x.data_ptr(), n, lh, lw, out.data_ptr(), fmt, brg_ptr,
+                                            _lib.stream_ptr()))
+        return out, brg
+
+    def forward(self, x: torch.Tensor, bridges: bool = True):
+        """y_q (B,channels_bn,h,w) -> (x_r list [full-res, None, ...], fx_brg list) as the reference."""
+        out, brg = self._run(x, _lib.FMT_F32_NCHW, bridges)
+        x_r = [out] + [None] * (self._dims[3] - 1)
+        return x_r, brg + [out]
+
+    def forward_u8(self, x: torch.Tensor) -> torch.Tensor:
+        """y_q -> (B,H,W,C) uint8 tiles; fuses the *255 / clip / truncate / HWC epilogue of codec.decode."""
+        out, _ = self._run(x, _lib.FMT_U8_HWC, False)
+        return out

@@ -1,0 +1,122 @@
+/* libcae_hip.so -- C ABI of the MI355X-native compress/decompress hot path.
+ *
+ * The reference (TheJacksonLaboratory/cnn_autoencoder) is pure Python: it has no FFI of its
+ * own.  Its native code on this path lives in the third-party package `compressai`
+ * (C++ pybind11: `_CXX.pmf_to_quantized_cdf`, `ans.RansEncoder/RansDecoder`) and in the
+ * ATen/cuDNN kernels behind `nn.Conv2d` / `nn.ConvTranspose2d` / `GDN`.  Each entry point
+ * below names the reference interface (file:line under /root/reference/src) it replaces;
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative cae_status otherwise;
+ *     cae_last_error() returns a thread-local message for the last failure;
+ *   - `*_dev` pointers are DEVICE pointers (HBM) of the current HIP device, `stream` is a
+ *     hipStream_t passed as void* (NULL = default stream); all launches are asynchronous;
+ *   - `*_host` pointers are host memory;
+ *   - outputs are caller-allocated, except the variable-length bitstreams returned by
+ *     cae_rans_encode_batch (library-allocated, release with cae_free);
+ *   - a model handle may be used from several host threads (dask's threaded scheduler calls
+ *     codec.encode concurrently, compress.py:121-128): entry points taking a handle
+ *     serialise on a per-handle mutex.
+ *   - no torch types anywhere in this ABI.
+ */
+#ifndef CAE_HIP_H
+#define CAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cae_model cae_model_t;
+
+enum cae_status {
+    CAE_OK = 0,
+    CAE_ERR_ARG = -1,      /* bad argument (the reference raises ValueError) */
+    CAE_ERR_HIP = -2,      /* HIP runtime failure */
+    CAE_ERR_NOMEM = -3,
+    CAE_ERR_UNSUPPORTED = -4,
+    CAE_ERR_CORRUPT = -5   /* bitstream ran past its end */
+};
+
+enum cae_track { CAE_ANALYSIS = 0, CAE_SYNTHESIS = 1 };
+enum cae_pixfmt {
+    CAE_FMT_U8_HWC = 0,  /* (n,h,w,c) uint8  -- zarr chunk layout, compress.py:101 */
+    CAE_FMT_F32_NCHW = 1 /* (n,c,h,w) float  -- nn.Module call surface */
+};
+
+int cae_version(void);
+const char *cae_last_error(void);
+void cae_free(void *p);
+
+/* ---- model lifecycle ------------------------------------------------------------------
+ * Replaces setup_modules / load_state_dict (_autoencoders.py:458-502): the Python side reads
+ * the checkpoint dict and hands every layer's tensors over in the reference's own layouts. */
+int cae_model_create(int channels_org, int channels_net, int channels_bn, int compression_level,
+                     int kernel_size, cae_model_t **out);
+void cae_model_destroy(cae_model_t *m);
+
+/* One unit of a track: strided conv (analysis; DownsamplingUnit model.0, _autoencoders.py:78-85;
+ * weight (cout,cin,k,k)) or transposed conv (synthesis; UpsamplingUnit model.0, :204-211;
+ * weight (cin,cout,k,k)), optional bias (cout), optional GDN/IGDN (model.1, :29-30) given as
+ * the EFFECTIVE (re-parametrised, non-negative) beta (cout) and gamma (cout,cout). */
+int cae_model_set_layer(cae_model_t *m, int track, int index, int cin, int cout,
+                        const float *weight_host, const float *bias_host,
+                        const float *beta_eff_host, const float *gamma_eff_host);
+
+/* Integer tables of the factorized entropy model, as EntropyBottleneck.update() leaves them
+ * (_autoencoders.py:502): quantized_cdf (channels, cdf_stride) int32, cdf_length (channels),
+ * offset (channels), medians (channels) float. */
+int cae_model_set_entropy(cae_model_t *m, int channels, int cdf_stride, const int32_t *quantized_cdf_host,
+                          const int32_t *cdf_length_host, const int32_t *offset_host,
+                          const float *medians_host);
+
+/* ---- device hot path --------------------------------------------------------------------
+ * cae_analysis replaces Analyzer.forward (_autoencoders.py:359-361) including the uint8 ->
+ * float/255 conversion of ConvolutionalAutoencoder.encode (:542-545) when fmt is U8_HWC.
+ * latents_dev: (n, channels_bn, ceil(h/2^L), ceil(w/2^L)) float NCHW. */
+int cae_analysis(cae_model_t *m, const void *tiles_dev, int fmt, int n, int h, int w,
+                 float *latents_dev, void *stream);
+
+/* cae_synthesis replaces Synthesizer.forward (_autoencoders.py:442-455) and, for U8_HWC, the
+ * x*255 -> clip -> truncating uint8 -> HWC epilogue of ConvolutionalAutoencoder.decode
+ * (:576-580).  latents_dev (n, channels_bn, lh, lw) float NCHW; output (n, ., lh*2^L, lw*2^L).
+ * bridges_dev: NULL, or an array of compression_level-1 device pointers that receive the
+ * intermediate features fx_brg[i] (n, channels_net, lh*2^(i+1), lw*2^(i+1)) float NCHW. */
+int cae_synthesis(cae_model_t *m, const float *latents_dev, int n, int lh, int lw,
+                  void *out_dev, int fmt, float *const *bridges_dev, void *stream);
+
+/* One GDN / IGDN layer on an NCHW tensor (compressai.layers.GDN.forward; reference call site
+ * _autoencoders.py:29-30).  Uses the beta/gamma of layer `index` of `track`. */
+int cae_gdn_forward(cae_model_t *m, int track, int index, const float *x_dev, int n, int h, int w,
+                    float *y_dev, void *stream);
+
+/* EntropyBottleneck quantiser (compress(): symbols = round(y - median_c).int(), reference call
+ * site _autoencoders.py:549-551; decompress(): y_hat = symbols + median_c, :568-571).
+ * count = n * channels * hw elements in NCHW order, hw = spatial size per channel. */
+int cae_quantize(cae_model_t *m, const float *latents_dev, int n, int hw, int32_t *symbols_dev, void *stream);
+int cae_dequantize(cae_model_t *m, const int32_t *symbols_dev, int n, int hw, float *latents_dev, void *stream);
+
+/* ---- host entropy coding ---------------------------------------------------------------
+ * Replace compressai._CXX.pmf_to_quantized_cdf and compressai.ans.RansEncoder /
+ * RansDecoder (encode_with_indexes / decode_with_indexes), reached from
+ * EntropyBottleneck.update / compress / decompress (_autoencoders.py:502, :549-551, :568-571).
+ * Streams are coded independently (one per tile), in parallel on `threads` host threads
+ * (0 = hardware concurrency).  Symbol order inside a stream is (c, y, x) raster; the CDF row
+ * of a symbol is its channel c. */
+int cae_pmf_to_quantized_cdf(const float *pmf_host, int n, int precision, uint32_t *cdf_host /* n+1 */);
+
+/* symbols_host: (n_streams, channels, hw) int32.  On success out_bufs[i] (library-allocated,
+ * cae_free each) holds stream i and out_lens[i] its byte length. */
+int cae_rans_encode_batch(cae_model_t *m, const int32_t *symbols_host, int n_streams, int hw,
+                          uint8_t **out_bufs, size_t *out_lens, int threads);
+/* bufs[i]/lens[i]: stream i.  symbols_host out: (n_streams, channels, hw) int32. */
+int cae_rans_decode_batch(cae_model_t *m, const uint8_t *const *bufs, const size_t *lens, int n_streams,
+                          int hw, int32_t *symbols_host, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAE_HIP_H */
