@@ -220,6 +220,33 @@ int launch_gdn(int ct, bool inverse, const LayerArgs &a, hipStream_t st) {
     return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct);
 }
 
+struct ProfScope {
+    Model *m;
+    int track;
+    hipStream_t st;
+    std::vector<std::pair<void *, void *>> ev;
+    hipEvent_t cur = nullptr;
+    ProfScope(Model *m_, int track_, hipStream_t st_) : m(m_), track(track_), st(st_) {}
+    void begin() {
+        if (!m->profiling) return;
+        hipEvent_t a;
+        if (hipEventCreate(&a) != hipSuccess) return;
+        (void)hipEventRecord(a, st);
+        cur = a;
+    }
+    void end() {
+        if (!m->profiling || !cur) return;
+        hipEvent_t b;
+        if (hipEventCreate(&b) != hipSuccess) return;
+        (void)hipEventRecord(b, st);
+        ev.emplace_back((void *)cur, (void *)b);
+        cur = nullptr;
+    }
+    ~ProfScope() {
+        if (m->profiling && !ev.empty()) m->prof[track].push_back(std::move(ev));
+    }
+};
+
 static unsigned ew_grid(size_t total) {
     size_t b = (total + 255) / 256;
     return (unsigned)std::min<size_t>(std::max<size_t>(b, 1), 256 * 8 * 4);
@@ -349,6 +376,8 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
     if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
 
+    ProfScope prof(m, CAE_ANALYSIS, st);
+    prof.begin();
     const size_t tot = (size_t)n * p0 * h * w;
     if (fmt == CAE_FMT_U8_HWC)
         hipLaunchKernelGGL(u8hwc_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint8_t *)tiles,
@@ -357,6 +386,7 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
         hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)tiles,
                            (float *)m->ws[0], n, m->c_org, h * w, p0);
     HIP_TRY(hipGetLastError());
+    prof.end();
 
     const float *cur = (const float *)m->ws[0];
     int cur_planes = p0, ch = h, cw = w;
@@ -383,7 +413,9 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
         a.tiles_x = (a.OW + 15) / 16;
         a.tiles_y = (a.OH + 7) / 8;
         a.outfmt = last ? OUT_NCHW : OUT_C8;
+        prof.begin();
         if ((rc = launch_conv(m->ks, l.ct, l.gdn, a, st))) return rc;
+        prof.end();
         cur = (const float *)a.out;
         cur_planes = l.ct * 4;
         ch = a.OH;
@@ -419,10 +451,13 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
     if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
 
+    ProfScope prof(m, CAE_SYNTHESIS, st);
+    prof.begin();
     const size_t tot = (size_t)n * p0 * lh * lw;
     hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (float *)m->ws[0], n, m->c_bn,
                        lh * lw, p0);
     HIP_TRY(hipGetLastError());
+    prof.end();
 
     const float *cur = (const float *)m->ws[0];
     int cur_planes = p0, ch = lh, cw = lw;
@@ -449,7 +484,9 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
         a.tiles_x = (cw + 31) / 32;
         a.tiles_y = (ch + 3) / 4;
         a.outfmt = last ? (fmt == CAE_FMT_U8_HWC ? OUT_U8HWC : OUT_NCHW) : OUT_C8;
+        prof.begin();
         if ((rc = launch_deconv(m->ks, l.ct, l.gdn, a, st))) return rc;
+        prof.end();
         if (!last && bridges && bridges[i]) {
             const size_t t2 = (size_t)n * l.cout * a.OH * a.OW;
             hipLaunchKernelGGL(c8_to_nchw_kernel, dim3(ew_grid(t2)), dim3(256), 0, st, (const float *)a.out, bridges[i],
@@ -496,6 +533,40 @@ int cae_gdn_forward(cae_model_t *mm, int track, int index, const float *x, int n
     a.cout = l.cout;
     a.outfmt = OUT_NCHW;
     return launch_gdn(l.ct, track == CAE_SYNTHESIS, a, st);
+}
+
+int cae_model_set_profiling(cae_model_t *mm, int enable) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m) return fail(CAE_ERR_ARG, "NULL model");
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->profiling = enable != 0;
+    return CAE_OK;
+}
+
+int cae_model_get_profile(cae_model_t *mm, int track, double *ms, int n_slots, int *calls, int reset) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !ms || n_slots < 1) return fail(CAE_ERR_ARG, "NULL argument");
+    if (track != CAE_ANALYSIS && track != CAE_SYNTHESIS) return fail(CAE_ERR_ARG, "bad track %d", track);
+    std::lock_guard<std::mutex> lk(m->mu);
+    for (int i = 0; i < n_slots; ++i) ms[i] = 0.0;
+    auto &calls_v = m->prof[track];
+    for (auto &call : calls_v)
+        for (size_t i = 0; i < call.size(); ++i) {
+            HIP_TRY(hipEventSynchronize((hipEvent_t)call[i].second));
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, (hipEvent_t)call[i].first, (hipEvent_t)call[i].second));
+            if ((int)i < n_slots) ms[i] += t;
+        }
+    if (calls) *calls = (int)calls_v.size();
+    if (reset) {
+        for (auto &call : calls_v)
+            for (auto &e : call) {
+                (void)hipEventDestroy((hipEvent_t)e.first);
+                (void)hipEventDestroy((hipEvent_t)e.second);
+            }
+        calls_v.clear();
+    }
+    return CAE_OK;
 }
 
 int cae_quantize(cae_model_t *mm, const float *latents, int n, int hw, int32_t *symbols, void *stream) {

@@ -4,6 +4,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace cae {
@@ -47,6 +48,9 @@ struct Model {
     void *ws[3] = {nullptr, nullptr, nullptr};
     size_t ws_bytes[3] = {0, 0, 0};
     std::mutex mu;
+    // profiling: per track, per profiled call, the event pairs of every launched kernel
+    bool profiling = false;
+    std::vector<std::vector<std::pair<void *, void *>>> prof[2];
     int ensure_ws(int which, size_t bytes);
     int ensure_device();
     ~Model();

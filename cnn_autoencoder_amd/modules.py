@@ -187,6 +187,19 @@ class _Track(nn.Module):
             self._versions = ver
         return self._handle
 
+    def set_profiling(self, enable: bool):
+        """Bracket every kernel of this track with HIP events (see cae_model_set_profiling)."""
+        _lib.check(_lib.lib().cae_model_set_profiling(self._sync().ptr, int(bool(enable))))
+
+    def get_profile(self, reset: bool = True):
+        """-> (ms per slot summed over calls [layout conversion, layer 0, layer 1, ...], number of calls)."""
+        n = self._dims[3] + 1
+        ms = (ctypes.c_double * n)()
+        calls = ctypes.c_int(0)
+        _lib.check(_lib.lib().cae_model_get_profile(self._sync().ptr, self._track_id, ms, n, ctypes.byref(calls),
+                                                    int(reset)))
+        return list(ms), calls.value
+
     def _gdn_forward(self, index: int, x: torch.Tensor) -> torch.Tensor:
         dev = _lib.require_gpu()
         h = self._sync()

@@ -1,0 +1,113 @@
+"""Sharded whole-slide compress / decompress driver (one process per GPU).
+
+The reference codes one zarr chunk per dask task, batch 1, on a single device
+(``compress.py:121-128``, ``_autoencoders.py:544``).  Tiles are independent units, so a slide's
+tiles are split into contiguous blocks over the ranks of a ``torch.distributed`` job with NO
+data-path collective: every rank codes its own tiles (and would write its own chunk files).  The
+only exchange is one ``all_gather`` (RCCL over xGMI on GPUs, gloo on CPU) of a fixed-width per-tile
+statistics record from which every rank derives the slide's rate and distortion
+(bpp = 8*bytes/(H*W) as ``test_cae.py:73``; PSNR from the float64 SSE, ``test_cae.py:60-68`` without
+its uint8 wrap-around).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+STATS_WIDTH = 3  # per tile: [compressed bytes, sum of squared error, number of pixel samples]
+
+
+def tile_range(rank: int, world: int, n_tiles: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of rank `rank` in chunk raster order."""
+    if not (0 <= rank < world) or n_tiles < 0:
+        raise ValueError(f'bad partition request rank={rank} world={world} n_tiles={n_tiles}')
+    base, rem = divmod(n_tiles, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def tile_stats(nbytes: Sequence[int], sse: Sequence[float], n_samples: int) -> torch.Tensor:
+    """(n_tiles, 3) float64 record; bytes and counts are exact in float64 below 2^53."""
+    out = torch.empty((len(nbytes), STATS_WIDTH), dtype=torch.float64)
+    out[:, 0] = torch.tensor(list(nbytes), dtype=torch.float64)
+    out[:, 1] = torch.tensor(list(sse), dtype=torch.float64)
+    out[:, 2] = float(n_samples)
+    return out
+
+
+def gather_stats(local: torch.Tensor, counts: Sequence[int] = None) -> torch.Tensor:
+    """all_gather of per-tile records over the default process group -> (total_tiles, 3) on every rank.
+
+    Ranks may hold different tile counts (ragged last block): records are padded to the largest
+    count for the collective and trimmed afterwards.
+    """
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local.clone()
+    world = dist.get_world_size()
+    dev = local.device
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    all_n = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(all_n, n_local)
+    all_n = [int(t.item()) for t in all_n]
+    width = max(all_n)
+    padded = torch.zeros((width, STATS_WIDTH), dtype=torch.float64, device=dev)
+    padded[:local.shape[0]] = local
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded)
+    return torch.cat([b[:n] for b, n in zip(bufs, all_n)], dim=0)
+
+
+def slide_summary(stats: torch.Tensor, pixels_per_tile: int) -> Dict[str, float]:
+    """Slide-level rate / distortion from the gathered records."""
+    s = stats.double().cpu()
+    nbytes = float(s[:, 0].sum())
+    sse = float(s[:, 1].sum())
+    n = float(s[:, 2].sum())
+    n_tiles = s.shape[0]
+    mse = sse / max(n, 1.0)
+    return dict(tiles=n_tiles, bytes=nbytes, bpp=8.0 * nbytes / max(n_tiles * pixels_per_tile, 1),
+                mse=mse, rmse=math.sqrt(mse), psnr=(10.0 * math.log10(255.0 ** 2 / mse) if mse > 0 else float('inf')))
+
+
+class SlideCoder:
+    """Batched compress -> decompress of resident tile batches on this rank's GPU."""
+
+    def __init__(self, codec, coder_threads: int = 0):
+        from .codec import _module
+        self.codec = codec
+        self.enc = _module(codec._model['encoder'])
+        self.dec = _module(codec._model['decoder'])
+        self.eb = _module(codec._model['fact_ent'])
+        self.level = len(self.dec.synthesis_track)
+        self.coder_threads = coder_threads
+
+    @torch.no_grad()
+    def compress(self, tiles_dev: torch.Tensor) -> List[bytes]:
+        """tiles_dev (n,h,w,c) uint8 in HBM -> rANS payloads (without the 16-byte chunk header)."""
+        y = self.enc.forward_u8(tiles_dev)
+        sym = self.eb.quantize_symbols(y)
+        sym_host = sym.reshape(sym.size(0), sym.size(1), -1).cpu().numpy()
+        return self.eb.encode_symbols(sym_host, self.coder_threads)
+
+    @torch.no_grad()
+    def decompress(self, payloads: Sequence[bytes], h: int, w: int) -> torch.Tensor:
+        """payloads -> (n,h,w,c) uint8 in HBM."""
+        size = (h // 2 ** self.level, w // 2 ** self.level)
+        y_q = self.eb.decompress(payloads, size)
+        return self.dec.forward_u8(y_q)
+
+    @torch.no_grad()
+    def roundtrip(self, tiles_dev: torch.Tensor) -> Tuple[List[bytes], torch.Tensor, torch.Tensor]:
+        """-> (payloads, reconstructed tiles in HBM, (n,3) float64 stats on the host)."""
+        n, h, w, c = tiles_dev.shape
+        payloads = self.compress(tiles_dev)
+        rec = self.decompress(payloads, h, w)
+        diff = rec.to(torch.float32) - tiles_dev.to(torch.float32)
+        sse = (diff * diff).reshape(n, -1).sum(dim=1, dtype=torch.float64).cpu()
+        stats = tile_stats([len(p) + 16 for p in payloads], sse.tolist(), h * w * c)
+        return payloads, rec, stats

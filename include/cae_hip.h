@@ -99,6 +99,16 @@ int cae_gdn_forward(cae_model_t *m, int track, int index, const float *x_dev, in
 int cae_quantize(cae_model_t *m, const float *latents_dev, int n, int hw, int32_t *symbols_dev, void *stream);
 int cae_dequantize(cae_model_t *m, const int32_t *symbols_dev, int n, int hw, float *latents_dev, void *stream);
 
+/* ---- measurement ------------------------------------------------------------------------
+ * With profiling on, cae_analysis / cae_synthesis bracket every kernel they launch with HIP
+ * events on the caller's stream.  cae_model_get_profile synchronises those events and ADDS the
+ * elapsed milliseconds of every call since the last reset into ms[0..n_slots): slot 0 is the
+ * input layout conversion, slot 1+i the fused kernel of layer i (conv/deconv + bias + GDN).
+ * calls receives the number of profiled calls.  (No reference counterpart: the reference only
+ * takes perf_counter wall times, test_cae.py:101-115.) */
+int cae_model_set_profiling(cae_model_t *m, int enable);
+int cae_model_get_profile(cae_model_t *m, int track, double *ms, int n_slots, int *calls, int reset);
+
 /* ---- host entropy coding ---------------------------------------------------------------
  * Replace compressai._CXX.pmf_to_quantized_cdf and compressai.ans.RansEncoder /
  * RansDecoder (encode_with_indexes / decode_with_indexes), reached from
