@@ -269,8 +269,8 @@ int cae_model_create(int channels_org, int channels_net, int channels_bn, int co
         return fail(CAE_ERR_ARG, "bad model dimensions");
     if (kernel_size != 3 && kernel_size != 5)
         return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", kernel_size);
-    if (round_ct(channels_net) < 0 || round_ct(channels_bn) < 0 || round_ct(channels_org) < 0)
-        return fail(CAE_ERR_UNSUPPORTED, "more than 192 channels per layer not supported");
+    // (the 192-channel limit of the conv kernels is enforced per layer in cae_model_set_layer;
+    //  a handle that only carries entropy tables may have any number of channels)
     Model *m = new Model();
     m->c_org = channels_org;
     m->c_net = channels_net;

@@ -115,6 +115,10 @@ int encode_stream(const EntropyTables &T, const int32_t *symbols, int hw, uint8_
             bool esc;
             classify(s[i], off, maxv, v, raw, esc);
             steps += 1;
+            // the escape code carries raw in 4-bit digits counted by a 32-bit shift loop upstream:
+            // values with raw >= 2^28 are not representable (upstream shifts by 32 there)
+            if (raw >= (1u << 28) || s[i] > (1 << 27) || s[i] < -(1 << 27))
+                return fail(CAE_ERR_ARG, "symbol %d (channel %d) is outside the codable range", s[i], c);
             if (esc) {
                 const int nb = bypass_digits(raw);
                 steps += (size_t)(nb / (int)kMaxBypass) + 1 + nb;

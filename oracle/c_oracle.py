@@ -59,6 +59,8 @@ def rans_encode_with_indexes(symbols, indexes, cdfs, cdf_lengths, offsets) -> by
         _p(symbols, ctypes.c_int32), _p(indexes, ctypes.c_int32), ctypes.c_long(len(symbols)),
         _p(cdfs, ctypes.c_int32), ctypes.c_int(cdfs.shape[1]), _p(lens, ctypes.c_int32),
         _p(offs, ctypes.c_int32), _p(out, ctypes.c_uint8), ctypes.c_long(cap))
+    if n == -2:
+        raise ValueError('symbol outside the codable range')
     if n < 0:
         raise RuntimeError('oracle encode failed')
     return out[:n].tobytes()

@@ -207,6 +207,8 @@ def rans_symbolize(symbols, indexes, cdfs, cdf_lengths, offsets):
         elif value >= max_value:
             raw_val = 2 * (value - max_value)
             value = max_value
+        if raw_val >= (1 << 28):
+            raise ValueError('symbol outside the codable range (upstream shifts a uint32 by 32 here)')
         syms.append((int(cdf[value]) & 0xFFFF, (int(cdf[value + 1]) - int(cdf[value])) & 0xFFFF, False))
         if value == max_value:
             n_bypass = 0

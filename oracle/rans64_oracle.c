@@ -148,6 +148,10 @@ long oracle_rans_encode_with_indexes(const int32_t *symbols, const int32_t *inde
             raw_val = (uint32_t)(2 * (value - max_value));
             value = max_value;
         }
+        if (raw_val >= (1u << 28)) { /* upstream shifts a uint32 by 32 here (undefined) */
+            free(syms);
+            return -2;
+        }
         PUSH(cdf[value], cdf[value + 1] - cdf[value], 0);
         if (value == max_value) {
             int32_t n_bypass = 0;

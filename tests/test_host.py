@@ -1,0 +1,311 @@
+"""CPU tests of the product's host side: the C ABI surface, the host entropy coder inside
+libcae_hip.so (checked against the oracle), the nn.Module / codec boundary and the slide driver.
+No device entry point is called here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+from conftest import GOLD, ROOT
+from oracle import c_oracle as C
+from oracle import cae_oracle as O
+
+
+@pytest.fixture(scope='module')
+def cae(built_lib):
+    import cnn_autoencoder_amd as cae
+    return cae
+
+
+def test_abi_exports_every_declared_symbol(cae):
+    from cnn_autoencoder_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'cae_hip.h')).read()
+    declared = set(re.findall(r'\b(cae_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = ctypes.CDLL(cae.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _lib.lib().cae_version() == 1
+
+
+def test_no_product_module_touches_the_oracle():
+    pkg = os.path.join(ROOT, 'cnn_autoencoder_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.cpp', '.hpp', '.h')) or f == 'Makefile':
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in text.lower().replace('# oracle-free', ''), f'{f} mentions the oracle'
+
+
+def test_missing_gpu_fails_loudly(cae):
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    enc = cae.Analyzer(3, 8, 16, 3, act_layer_type='GDN')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        enc(torch.rand(1, 3, 16, 16))
+    eb = cae.EntropyBottleneck(4)
+    eb.update()
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        eb.compress(torch.rand(1, 4, 2, 2))
+
+
+# ---- quantised CDF ------------------------------------------------------------------------------
+pmfs = st.lists(st.floats(min_value=0, max_value=1, allow_nan=False, width=32), min_size=2, max_size=60).filter(
+    lambda p: sum(p) > 1e-3)
+
+
+@settings(max_examples=150, deadline=None)
+@given(pmfs)
+def test_product_cdf_equals_oracle(p):
+    from cnn_autoencoder_amd.entropy import pmf_to_quantized_cdf
+    p = np.asarray(p, dtype=np.float32)
+    p = p / p.sum()
+    if (np.round(p * 65536) > 1).sum() == 0:
+        return
+    assert pmf_to_quantized_cdf(torch.from_numpy(p)).tolist() == O.pmf_to_quantized_cdf(p.tolist())
+
+
+def test_product_cdf_rejects_bad_pmf(cae):
+    from cnn_autoencoder_amd.entropy import pmf_to_quantized_cdf
+    with pytest.raises(ValueError):
+        pmf_to_quantized_cdf(torch.tensor([0.5, float('nan')]))
+    with pytest.raises(ValueError):
+        pmf_to_quantized_cdf(torch.tensor([0.5, -0.1]))
+    with pytest.raises(ValueError):
+        pmf_to_quantized_cdf(torch.tensor([0.0, 0.0]))
+
+
+# ---- host rANS coder ----------------------------------------------------------------------------
+class _Tables:
+    """Drives cae_rans_{encode,decode}_batch with explicit integer tables."""
+
+    def __init__(self, cdf, lens, off):
+        from cnn_autoencoder_amd import _lib
+        self._lib = _lib
+        self.cdf = np.ascontiguousarray(cdf, dtype=np.int32)
+        self.lens = np.ascontiguousarray(lens, dtype=np.int32)
+        self.off = np.ascontiguousarray(off, dtype=np.int32)
+        self.C = self.cdf.shape[0]
+        self.h = _lib.Handle(1, 1, self.C, 1, 3)
+        med = np.zeros(self.C, dtype=np.float32)
+        _lib.check(_lib.lib().cae_model_set_entropy(self.h.ptr, self.C, self.cdf.shape[1], self.cdf.ctypes.data,
+                                                    self.lens.ctypes.data, self.off.ctypes.data, med.ctypes.data))
+
+    def encode(self, sym, threads=0):
+        sym = np.ascontiguousarray(sym, dtype=np.int32)
+        n, hw = sym.shape[0], sym.shape[2]
+        bufs = (ctypes.c_void_p * n)()
+        lens = (ctypes.c_size_t * n)()
+        self._lib.check(self._lib.lib().cae_rans_encode_batch(self.h.ptr, sym.ctypes.data, n, hw, bufs, lens, threads))
+        out = [ctypes.string_at(bufs[i], lens[i]) for i in range(n)]
+        for i in range(n):
+            self._lib.lib().cae_free(bufs[i])
+        return out
+
+    def decode(self, strings, hw, threads=0):
+        n = len(strings)
+        bufs = (ctypes.c_char_p * n)(*strings)
+        lens = (ctypes.c_size_t * n)(*[len(s) for s in strings])
+        sym = np.empty((n, self.C, hw), dtype=np.int32)
+        self._lib.check(self._lib.lib().cae_rans_decode_batch(self.h.ptr, bufs, lens, n, hw, sym.ctypes.data, threads))
+        return sym
+
+    def oracle_encode(self, sym_one):
+        idx = np.repeat(np.arange(self.C), sym_one.shape[1]).astype(np.int32)
+        return C.rans_encode_with_indexes(sym_one.reshape(-1), idx, self.cdf, self.lens, self.off)
+
+
+def test_product_coder_known_answers(cae):
+    import json
+    kat = json.load(open(os.path.join(GOLD, 'rans_kat.json')))['rans']
+    for k in kat:
+        t = _Tables(k['cdf'], k['cdf_length'], k['offset'])
+        sym = np.asarray(k['symbols'], dtype=np.int32).reshape(1, len(k['cdf']), k['hw'])
+        assert t.encode(sym)[0].hex() == k['bytes_hex'], k['name']
+        assert np.array_equal(t.decode([bytes.fromhex(k['bytes_hex'])], k['hw']), sym)
+
+
+@pytest.mark.parametrize('seed,spread', [(0, 2), (1, 6), (2, 40), (3, 5000), (4, 2 ** 20), (5, 2 ** 26)])
+def test_product_coder_bit_exact_vs_oracle(cae, seed, spread):
+    from test_oracle import _random_tables
+    rng = np.random.default_rng(100 + seed)
+    channels, hw, n = int(rng.integers(1, 9)), int(rng.integers(1, 64)), 5
+    cdf, lens, off = _random_tables(rng, channels, 40)
+    t = _Tables(cdf, lens, off)
+    sym = rng.integers(-spread, spread + 1, (n, channels, hw)).astype(np.int32)
+    for threads in (1, 3):
+        out = t.encode(sym, threads)
+        assert out == [t.oracle_encode(sym[i]) for i in range(n)]
+        assert np.array_equal(t.decode(out, hw, threads), sym)
+
+
+def test_out_of_range_symbols_are_rejected_not_hung(cae):
+    t = _Tables([[0, 32768, 65536]], [3], [0])
+    with pytest.raises(ValueError, match='codable range'):
+        t.encode(np.asarray([[[2 ** 29]]], dtype=np.int32))
+    with pytest.raises(ValueError):
+        C.rans_encode_with_indexes(np.asarray([2 ** 29], dtype=np.int32), np.zeros(1, dtype=np.int32),
+                                   np.asarray([[0, 32768, 65536]], dtype=np.int32), [3], [0])
+
+
+def test_reciprocal_division_is_exact_for_every_frequency(cae):
+    """The encoder replaces x / freq by a fixed-point reciprocal multiply: compare with the oracle's
+    plain division for every frequency 1..65535 (two-bin rows [0, f, 65536])."""
+    freqs = np.arange(1, 65536, dtype=np.int64)
+    rng = np.random.default_rng(7)
+    for block in np.array_split(freqs, 64):
+        cdf = np.zeros((len(block), 3), dtype=np.int32)
+        cdf[:, 1] = block
+        cdf[:, 2] = 65536
+        lens = np.full(len(block), 3, dtype=np.int32)
+        off = np.zeros(len(block), dtype=np.int32)
+        t = _Tables(cdf, lens, off)
+        sym = rng.integers(0, 2, (1, len(block), 24)).astype(np.int32)  # value 1 = escape bin (freq 65536-f)
+        assert t.encode(sym, 1)[0] == t.oracle_encode(sym[0])
+
+
+def test_corrupt_and_short_streams_raise(cae):
+    rng = np.random.default_rng(0)
+    from test_oracle import _random_tables
+    cdf, lens, off = _random_tables(rng, 3, 10)
+    t = _Tables(cdf, lens, off)
+    sym = rng.integers(-3, 4, (1, 3, 50)).astype(np.int32)
+    s = t.encode(sym)[0]
+    with pytest.raises(cae.CaeError, match='bitstream'):
+        t.decode([s[:4]], 50)
+    with pytest.raises(cae.CaeError, match='bitstream'):
+        t.decode([b'\x00' * 8], 50)  # state 0 keeps pulling words past the end
+    with pytest.raises(ValueError):
+        t.encode(sym[:0])
+
+
+# ---- nn.Module / checkpoint / codec boundary ----------------------------------------------------
+def test_init_and_state_dict_keys_match_reference_fixture(cae):
+    g = np.load(os.path.join(GOLD, 'ref_init_seed0.npz'))
+    torch.manual_seed(0)
+    enc = cae.Analyzer(3, 8, 16, 3, act_layer_type='GDN')
+    dec = cae.Synthesizer(3, 8, 16, 3, act_layer_type='GDN')
+    sd = {**{'encoder/' + k: v for k, v in enc.state_dict().items()},
+          **{'decoder/' + k: v for k, v in dec.state_dict().items()}}
+    for k in g.files:  # every tensor the reference's modules hold, bit for bit under the same seed
+        assert np.array_equal(g[k], sd[k].numpy()), k
+    extra = [k for k in sd if k not in g.files]
+    assert all(re.search(r'(beta|gamma)_reparam\.(pedestal|lower_bound\.bound)$', k) for k in extra)
+    assert len(enc.analysis_track) == 3 and len(dec.synthesis_track) == 3 and dec.rec_level == 3
+
+
+def test_unsupported_variants_say_so(cae):
+    for kw in (dict(act_layer_type='LeakyReLU'), dict(use_residual=True), dict(batch_norm=True), dict(groups=True),
+               dict(channels_expansion=2), dict(kernel_size=7)):
+        with pytest.raises(NotImplementedError):
+            cae.Analyzer(3, 8, 16, 3, **kw)
+    with pytest.raises(NotImplementedError):
+        cae.Synthesizer(3, 8, 16, 3, multiscale_analysis=True)
+
+
+def test_checkpoint_schema_round_trip(cae, tmp_path):
+    from cnn_autoencoder_amd import synth
+    cfg = dict(synth.CANONICAL, channels_net=8, channels_bn=16, compression_level=3)
+    state = synth.synthetic_state(cfg, seed=3)
+    model = cae.autoencoder_from_state_dict(state)
+    assert set(model) == {'encoder', 'decoder', 'fact_ent'}
+    for k in model:
+        assert isinstance(model[k], torch.nn.DataParallel) and not model[k].training
+    fe = model['fact_ent'].module
+    assert fe.channels == 16 and fe.filters == (3, 3, 3, 3) and fe._quantized_cdf.shape[0] == 16
+    # what utils.checkpoint writes: args + module state_dicts (incl. the derived integer buffers)
+    ckpt = dict(cfg, encoder=model['encoder'].module.state_dict(), decoder=model['decoder'].module.state_dict(),
+                fact_ent=fe.state_dict())
+    path = str(tmp_path / 'last_ckpt.pth')
+    torch.save(ckpt, path)
+    again = cae.autoencoder_from_state_dict(path)
+    assert torch.equal(again['fact_ent'].module._quantized_cdf, fe._quantized_cdf)
+    for a, b in zip(again['encoder'].module.parameters(), model['encoder'].module.parameters()):
+        assert torch.equal(a, b)
+    # only some modules enabled
+    only = cae.autoencoder_from_state_dict(dict(state, enabled_modules=['decoder']))
+    assert set(only) == {'decoder'}
+
+
+def test_entropy_module_matches_oracle_on_cpu(cae):
+    torch.manual_seed(1)
+    eb = cae.EntropyBottleneck(10, filters=[3] * 4).eval()
+    eb.update(force=True)
+    o = O.EntropyBottleneckOracle(10)
+    o.load(eb.state_dict())
+    o.update()
+    assert torch.equal(o._quantized_cdf, eb._quantized_cdf)
+    assert torch.equal(o._cdf_length, eb._cdf_length) and torch.equal(o._offset, eb._offset)
+    x = torch.randn(2, 10, 4, 3) * 7
+    a, b = eb(x)
+    c, d = o.forward(x)
+    assert torch.equal(a, c) and torch.equal(b, d)
+    assert torch.allclose(eb.loss(), o.loss())
+    eb.train()
+    yn, _ = eb(x)
+    assert ((yn - x).abs() <= 0.5).all() and not torch.equal(yn, x)
+    eb.fit_quantiles()
+    assert float(eb.loss()) < 1e-2
+    eb.update(force=True)
+    assert int(eb._cdf_length.min()) > 100  # support widened to the 1e-9 tails
+    # host coder of the module (no GPU needed): bit-exact vs the oracle coder
+    o.load(eb.state_dict())
+    o.update()
+    sym = torch.round(x * 9).int().reshape(2, 10, -1).numpy()
+    strings = eb.encode_symbols(sym)
+    idx = np.repeat(np.arange(10), sym.shape[2])
+    for i in range(2):
+        assert strings[i] == C.rans_encode_with_indexes(sym[i].reshape(-1), idx, o._quantized_cdf.numpy(),
+                                                        o._cdf_length.numpy(), o._offset.numpy())
+    assert np.array_equal(eb.decode_symbols(strings, sym.shape[2]), sym)
+
+
+def test_entropy_state_dict_loads_integer_buffers(cae):
+    torch.manual_seed(2)
+    a = cae.EntropyBottleneck(6)
+    a.update()
+    b = cae.EntropyBottleneck(6)
+    b.load_state_dict(a.state_dict())  # strict: sizes of the integer buffers differ before loading
+    assert torch.equal(b._quantized_cdf, a._quantized_cdf) and torch.equal(b._cdf_length, a._cdf_length)
+    assert 'likelihood_lower_bound.bound' in a.state_dict() and 'target' in a.state_dict()
+
+
+def test_bottleneck_codec_config_round_trip(cae):
+    torch.manual_seed(4)
+    eb = cae.EntropyBottleneck(8, filters=[3] * 4)
+    codec = cae.ConvolutionalAutoencoderBottleneck(channels_bn=8, fact_ent=eb)
+    cfg = codec.get_config()
+    assert cfg['id'] == 'cae_bn' and set(cfg) == {'id', 'filters', 'channels_bn', 'fact_ent_checkpoint'}
+    import json
+    clone = cae.ConvolutionalAutoencoderBottleneck.from_config(json.loads(json.dumps(cfg)))
+    assert torch.equal(clone._fact_ent._quantized_cdf.cpu(), codec._fact_ent._quantized_cdf.cpu())
+    assert cae.ConvolutionalAutoencoder.codec_id == 'cae'
+
+
+# ---- slide driver -------------------------------------------------------------------------------
+@settings(max_examples=100, deadline=None)
+@given(st.integers(1, 16), st.integers(0, 5000))
+def test_tile_range_partitions_the_slide(world, n_tiles):
+    from cnn_autoencoder_amd import slide
+    ranges = [slide.tile_range(r, world, n_tiles) for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == n_tiles
+    assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    sizes = [hi - lo for lo, hi in ranges]
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_slide_summary_math():
+    from cnn_autoencoder_amd import slide
+    with pytest.raises(ValueError):
+        slide.tile_range(3, 2, 10)
+    st_ = slide.tile_stats([1000, 3000], [100.0, 300.0], 64 * 64 * 3)
+    s = slide.slide_summary(slide.gather_stats(st_), 64 * 64)
+    assert s['tiles'] == 2 and s['bytes'] == 4000
+    assert abs(s['bpp'] - 8 * 4000 / (2 * 64 * 64)) < 1e-12
+    mse = 400.0 / (2 * 64 * 64 * 3)
+    assert abs(s['psnr'] - 10 * np.log10(255 ** 2 / mse)) < 1e-9
