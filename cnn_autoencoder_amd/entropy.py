@@ -250,6 +250,18 @@ class EntropyBottleneck(nn.Module):
         _lib.check(_lib.lib().cae_quantize(h.ptr, x.data_ptr(), x.size(0), hw, sym.data_ptr(), _lib.stream_ptr()))
         return sym
 
+    @torch.no_grad()
+    def dequantize_symbols(self, sym: torch.Tensor) -> torch.Tensor:
+        """(B,C,...) int32 symbols on the GPU -> float latents symbols + median (HIP kernel)."""
+        dev = _lib.require_gpu()
+        h = self._sync_handle()
+        sym = sym.to(device=dev, dtype=torch.int32).contiguous()
+        hw = int(np.prod(sym.shape[2:]))
+        out = torch.empty(sym.shape, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().cae_dequantize(h.ptr, sym.data_ptr(), sym.size(0), hw, out.data_ptr(),
+                                             _lib.stream_ptr()))
+        return out
+
     def encode_symbols(self, sym_host: np.ndarray, threads: int = 0) -> List[bytes]:
         """(B,C,hw) int32 host symbols -> one rANS byte string per batch item."""
         h = self._sync_handle()
@@ -265,13 +277,20 @@ class EntropyBottleneck(nn.Module):
             _lib.lib().cae_free(bufs[i])
         return out
 
-    def decode_symbols(self, strings: Sequence[bytes], hw: int, threads: int = 0) -> np.ndarray:
+    def decode_symbols(self, strings: Sequence[bytes], hw: int, threads: int = 0,
+                       out: Optional[np.ndarray] = None) -> np.ndarray:
+        """rANS byte strings -> (B,C,hw) int32 host symbols (written into `out` when given)."""
         h = self._sync_handle()
         n = len(strings)
         keep = [bytes(s) for s in strings]
         bufs = (ctypes.c_char_p * n)(*keep)
         lens = (ctypes.c_size_t * n)(*[len(s) for s in keep])
-        sym = np.empty((n, self.channels, hw), dtype=np.int32)
+        if out is None:
+            sym = np.empty((n, self.channels, hw), dtype=np.int32)
+        else:
+            sym = out
+            if sym.shape != (n, self.channels, hw) or sym.dtype != np.int32 or not sym.flags.c_contiguous:
+                raise ValueError('out must be a C-contiguous int32 array of shape (B,C,hw)')
         _lib.check(_lib.lib().cae_rans_decode_batch(h.ptr, bufs, lens, n, hw, sym.ctypes.data, threads))
         return sym
 

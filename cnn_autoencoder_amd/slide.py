@@ -75,7 +75,12 @@ def slide_summary(stats: torch.Tensor, pixels_per_tile: int) -> Dict[str, float]
 
 
 class SlideCoder:
-    """Batched compress -> decompress of resident tile batches on this rank's GPU."""
+    """Batched compress -> decompress of resident tile batches on this rank's GPU.
+
+    ``run(batches)`` software-pipelines the batches: while the host range-codes batch k
+    (worker thread, GIL released inside libcae_hip.so), the GPU already runs the analysis of batch
+    k+1 and the synthesis of batch k-1.  Symbols cross PCIe through pinned buffers on a side stream.
+    """
 
     def __init__(self, codec, coder_threads: int = 0):
         from .codec import _module
@@ -85,7 +90,11 @@ class SlideCoder:
         self.eb = _module(codec._model['fact_ent'])
         self.level = len(self.dec.synthesis_track)
         self.coder_threads = coder_threads
+        self._pinned = {}
+        self._copy_stream = None
+        self.timers = {}
 
+    # ---- simple (unpipelined) entry points ---------------------------------------------------
     @torch.no_grad()
     def compress(self, tiles_dev: torch.Tensor) -> List[bytes]:
         """tiles_dev (n,h,w,c) uint8 in HBM -> rANS payloads (without the 16-byte chunk header)."""
@@ -102,12 +111,98 @@ class SlideCoder:
         return self.dec.forward_u8(y_q)
 
     @torch.no_grad()
+    def tile_sse(self, rec: torch.Tensor, tiles: torch.Tensor) -> torch.Tensor:
+        """per-tile sum of squared error of two (n,h,w,c) uint8 batches -> (n,) float64 on the GPU."""
+        n = tiles.shape[0]
+        d = rec.reshape(n, -1).to(torch.int16) - tiles.reshape(n, -1).to(torch.int16)
+        return (d.to(torch.int32) * d.to(torch.int32)).sum(dim=1, dtype=torch.int64).to(torch.float64)
+
+    @torch.no_grad()
     def roundtrip(self, tiles_dev: torch.Tensor) -> Tuple[List[bytes], torch.Tensor, torch.Tensor]:
         """-> (payloads, reconstructed tiles in HBM, (n,3) float64 stats on the host)."""
         n, h, w, c = tiles_dev.shape
         payloads = self.compress(tiles_dev)
         rec = self.decompress(payloads, h, w)
-        diff = rec.to(torch.float32) - tiles_dev.to(torch.float32)
-        sse = (diff * diff).reshape(n, -1).sum(dim=1, dtype=torch.float64).cpu()
+        sse = self.tile_sse(rec, tiles_dev).cpu()
         stats = tile_stats([len(p) + 16 for p in payloads], sse.tolist(), h * w * c)
         return payloads, rec, stats
+
+    # ---- pipelined slide pass ----------------------------------------------------------------
+    def _pin(self, key, shape, dtype):
+        buf = self._pinned.get(key)
+        if buf is None or buf.shape != tuple(shape) or buf.dtype != dtype:
+            buf = torch.empty(shape, dtype=dtype, pin_memory=True)
+            self._pinned[key] = buf
+        return buf
+
+    @torch.no_grad()
+    def run(self, batches: Sequence[torch.Tensor], keep_payloads: bool = False):
+        """Round-trip every batch ((n,h,w,c) uint8 in HBM).  -> (stats (sum n, 3) float64 host tensor,
+        payload lists if keep_payloads).  Work of batch k: A = analysis+quantise+D2H (GPU),
+        B = rANS encode + decode (host worker), D = H2D+dequantise+synthesis+SSE (GPU)."""
+        import time
+        from concurrent.futures import ThreadPoolExecutor
+        dev = batches[0].device
+        main = torch.cuda.current_stream(dev)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(dev)
+        copy = self._copy_stream
+        K = len(batches)
+        tm = dict(host_encode=0.0, host_decode=0.0, wait_host=0.0)
+        all_payloads, stats_parts = [], []
+
+        def stage_a(k):
+            t = batches[k]
+            y = self.enc.forward_u8(t)
+            sym = self.eb.quantize_symbols(y)
+            n, C = sym.size(0), sym.size(1)
+            hw = sym.numel() // (n * C)
+            pin = self._pin(('a', k & 1), (n, C, hw), torch.int32)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(copy):
+                copy.wait_event(ready)
+                pin.copy_(sym.reshape(n, C, hw), non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(copy)
+            sym.record_stream(copy)
+            return k, pin, done, hw
+
+        def host_code(k, pin, done, hw):
+            done.synchronize()
+            t0 = time.perf_counter()
+            payloads = self.eb.encode_symbols(pin.numpy(), self.coder_threads)
+            t1 = time.perf_counter()
+            back = self._pin(('d', k & 1), pin.shape, torch.int32)  # decode straight into pinned memory
+            self.eb.decode_symbols(payloads, hw, self.coder_threads, out=back.numpy())
+            t2 = time.perf_counter()
+            return payloads, back, t1 - t0, t2 - t1
+
+        def stage_d(k, payloads, back):
+            t = batches[k]
+            n, h, w, c = t.shape
+            sym = back.to(dev, non_blocking=True)
+            lh, lw = h // 2 ** self.level, w // 2 ** self.level
+            y_q = self.eb.dequantize_symbols(sym.reshape(n, self.eb.channels, lh, lw))
+            rec = self.dec.forward_u8(y_q)
+            sse = self.tile_sse(rec, t)
+            return sse, [len(p) + 16 for p in payloads], h * w * c
+
+        pending = []  # (sse tensor on GPU, nbytes list, samples)
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(host_code, *stage_a(0))
+            for k in range(K):
+                nxt = pool.submit(host_code, *stage_a(k + 1)) if k + 1 < K else None
+                t0 = time.perf_counter()
+                payloads, back, te, td = fut.result()
+                tm['wait_host'] += time.perf_counter() - t0
+                tm['host_encode'] += te
+                tm['host_decode'] += td
+                pending.append(stage_d(k, payloads, back))
+                if keep_payloads:
+                    all_payloads.append(payloads)
+                fut = nxt
+        for sse, nbytes, samples in pending:
+            stats_parts.append(tile_stats(nbytes, sse.cpu().tolist(), samples))
+        self.timers = tm
+        return torch.cat(stats_parts), all_payloads
