@@ -32,6 +32,18 @@ static constexpr uint32_t kMaxBypass = (1u << kBypassBits) - 1;
 static inline uint64_t mul_hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 
 void EntropyTables::build_tables() {
+    // decoder: bucket table over the top kLutBits of the 16-bit cumulative frequency
+    lut.assign((size_t)channels << kLutBits, 0);
+    for (int c = 0; c < channels; ++c) {
+        const int32_t *row = cdf.data() + (size_t)c * stride;
+        const int n = len[c];
+        int v = 0;
+        for (int b = 0; b < (1 << kLutBits); ++b) {
+            const int32_t cum = b << (16 - kLutBits);
+            while (v + 1 < n - 1 && row[v + 1] <= cum) ++v;
+            lut[((size_t)c << kLutBits) + b] = (uint16_t)v;
+        }
+    }
     enc.assign((size_t)channels * stride, EncSym{0, 0, 0, 0, 0});
     for (int c = 0; c < channels; ++c) {
         const int32_t *row = cdf.data() + (size_t)c * stride;
@@ -203,13 +215,13 @@ int decode_stream(const EntropyTables &T, const uint8_t *buf, size_t len, int hw
     for (int c = 0; c < T.channels; ++c) {
         const int32_t *row = T.cdf.data() + (size_t)c * T.stride;
         const int32_t n = T.len[c], maxv = n - 2, off = T.off[c];
+        const uint16_t *lutc = T.lut.data() + ((size_t)c << EntropyTables::kLutBits);
         int32_t *s = symbols + (size_t)c * hw;
         for (int i = 0; i < hw; ++i) {
             const uint32_t cum = (uint32_t)(x & 0xFFFFu);
-            // first k with row[k] > cum, minus one (row[0] = 0 <= cum always)
-            const int32_t *it = std::upper_bound(row, row + n, (int32_t)cum);
-            int32_t v = (int32_t)(it - row) - 1;
-            if (v > maxv) v = maxv;  // cum < 65536 = row[n-1], cannot happen on valid tables
+            // largest v with row[v] <= cum: start at the bucket's first symbol, scan forward
+            int32_t v = lutc[cum >> (16 - EntropyTables::kLutBits)];
+            while (v < maxv && (uint32_t)row[v + 1] <= cum) ++v;
             const uint32_t start = (uint32_t)row[v], freq = (uint32_t)(row[v + 1] - row[v]);
             x = (uint64_t)freq * (x >> kPrecision) + (x & 0xFFFFu) - start;
             if (x < kRansL) x = (x << 32) | r.next();

@@ -35,6 +35,8 @@ struct EntropyTables {
         uint32_t rcp_shift;
     };
     std::vector<EncSym> enc;  // [channels * stride]
+    static constexpr int kLutBits = 10;
+    std::vector<uint16_t> lut;  // [channels << kLutBits]: first symbol of each cumulative-frequency bucket
     void build_tables();
 };
 
