@@ -78,6 +78,41 @@ static std::vector<float> pack_gamma(const float *g, int C, int ct) {
     return out;
 }
 
+// first analysis layer (cin <= 4): [tap][ct][lane][2]: W(cout = 32ct + (lane&31), ch = 2j + (lane>>5), tap)
+static std::vector<float> pack_first(const float *w, int cin, int cout, int ks, int ct) {
+    std::vector<float> out((size_t)ks * ks * ct * 128, 0.0f);
+    size_t o = 0;
+    for (int tap = 0; tap < ks * ks; ++tap)
+        for (int t = 0; t < ct; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 2; ++j, ++o) {
+                    const int co = 32 * t + (lane & 31), ch = 2 * j + (lane >> 5);
+                    if (co < cout && ch < cin) out[o] = w[((size_t)co * cin + ch) * ks * ks + tap];
+                }
+    return out;
+}
+
+// last synthesis layer (cout <= 4): [nd][ndx][q][lane][s]:
+//   A(row = lane&15 = 4c + 2py + px, cin = 16q + 4(lane>>4) + s) = W[cin][c][2d+py+P][2dx+px+P]
+static std::vector<float> pack_last(const float *w, int cin, int cout, int ks) {
+    const int P = ks / 2, dlo = -((P + 1) / 2), dhi = (ks - 1 - P) / 2, nb = dhi - dlo + 1;
+    const int nq = (cin + 15) / 16;
+    std::vector<float> out((size_t)nb * nb * nq * 256, 0.0f);
+    size_t o = 0;
+    for (int nd = 0; nd < nb; ++nd)
+        for (int ndx = 0; ndx < nb; ++ndx)
+            for (int q = 0; q < nq; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s2 = 0; s2 < 4; ++s2, ++o) {
+                        const int row = lane & 15, c = row >> 2, py = (row >> 1) & 1, px = row & 1;
+                        const int ci = 16 * q + 4 * (lane >> 4) + s2;
+                        const int ky = 2 * (dlo + nd) + py + P, kx = 2 * (dlo + ndx) + px + P;
+                        if (c < cout && ci < cin && ky >= 0 && ky < ks && kx >= 0 && kx < ks)
+                            out[o] = w[(((size_t)ci * cout + c) * ks + ky) * ks + kx];
+                    }
+    return out;
+}
+
 static int upload(const std::vector<float> &v, float **dev) {
     if (*dev) {
         (void)hipFree(*dev);
@@ -122,6 +157,7 @@ Model::~Model() {
             if (l.bias) (void)hipFree(l.bias);
             if (l.gp) (void)hipFree(l.gp);
             if (l.beta) (void)hipFree(l.beta);
+            if (l.wp_edge) (void)hipFree(l.wp_edge);
         }
     for (int i = 0; i < 3; ++i)
         if (ws[i]) (void)hipFree(ws[i]);
@@ -171,6 +207,37 @@ static int launch_deconv_t(const LayerArgs &a, hipStream_t st) {
     return CAE_OK;
 }
 
+template <int KS, int CT, bool GDN>
+static int launch_first_t(const LayerArgs &a, const FirstArgs &f, hipStream_t st) {
+    constexpr int NW = 4;
+    constexpr int WH = 2 * 16 + KS - 2, HH = 4 * NW + KS - 2;
+    constexpr int LDS = 2 * (GDN ? CT * 4096 : 0) + KS * KS * CT * 512 + ((HH * WH * 16 + 1023) / 1024) * 1024;
+    auto kern = conv_first_kernel<KS, CT, NW, GDN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a, f);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+template <int KS>
+static int launch_last_t(const LayerArgs &a, hipStream_t st) {
+    constexpr int NW = 4;
+    constexpr int P = KS / 2;
+    constexpr int NB = (KS - 1 - P) / 2 + (P + 1) / 2 + 1;
+    const int lds = NB * NB * a.cci * 1024;
+    auto kern = deconv_last_kernel<KS, NW>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
 template <int CT, bool INV>
 static int launch_gdn_t(const LayerArgs &a, hipStream_t st) {
     constexpr int NW = 4;
@@ -198,6 +265,30 @@ int launch_conv(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
     } else if (ks == 5) {
         if (gdn) { DISPATCH_CT(launch_conv_t, 5, true) } else { DISPATCH_CT(launch_conv_t, 5, false) }
     }
+    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+}
+
+#define DISPATCH_CT_F(KS_, GDN_)                                                 \
+    switch (ct) {                                                                \
+        case 1: return launch_first_t<KS_, 1, GDN_>(a, f, st);                   \
+        case 2: return launch_first_t<KS_, 2, GDN_>(a, f, st);                   \
+        case 4: return launch_first_t<KS_, 4, GDN_>(a, f, st);                   \
+        case 6: return launch_first_t<KS_, 6, GDN_>(a, f, st);                   \
+        default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct); \
+    }
+
+int launch_first(int ks, int ct, bool gdn, const LayerArgs &a, const FirstArgs &f, hipStream_t st) {
+    if (ks == 3) {
+        if (gdn) { DISPATCH_CT_F(3, true) } else { DISPATCH_CT_F(3, false) }
+    } else if (ks == 5) {
+        if (gdn) { DISPATCH_CT_F(5, true) } else { DISPATCH_CT_F(5, false) }
+    }
+    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+}
+
+int launch_last(int ks, const LayerArgs &a, hipStream_t st) {
+    if (ks == 3) return launch_last_t<3>(a, st);
+    if (ks == 5) return launch_last_t<5>(a, st);
     return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
 }
 
@@ -318,6 +409,15 @@ int cae_model_set_layer(cae_model_t *mm, int track, int index, int cin, int cout
         (void)hipFree(l.bias);
         l.bias = nullptr;
     }
+    if (l.wp_edge) {
+        (void)hipFree(l.wp_edge);
+        l.wp_edge = nullptr;
+    }
+    if (track == CAE_ANALYSIS && index == 0 && cin <= 4) {
+        if ((rc = upload(pack_first(w, cin, cout, m->ks, ct), &l.wp_edge))) return rc;
+    } else if (track == CAE_SYNTHESIS && index == m->L - 1 && cout <= 4 && beta == nullptr) {
+        if ((rc = upload(pack_last(w, cin, cout, m->ks), &l.wp_edge))) return rc;
+    }
     l.gdn = beta != nullptr;
     if (l.gdn) {
         std::vector<float> b(ct * 32, 1.0f);
@@ -363,7 +463,7 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
 
     // workspace: ws[0] = converted input, ws[1]/ws[2] ping-pong
     const int p0 = (m->c_org + 7) / 8;
-    size_t in_bytes = (size_t)n * p0 * h * w * 32;
+    size_t in_bytes = m->enc[0].wp_edge ? 0 : (size_t)n * p0 * h * w * 32;  // fused first layer reads the tiles
     size_t maxact = 0;
     {
         int ch = h, cw = w;
@@ -377,15 +477,18 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
     if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
 
     ProfScope prof(m, CAE_ANALYSIS, st);
+    const bool first_fused = m->enc[0].wp_edge != nullptr;
     prof.begin();
-    const size_t tot = (size_t)n * p0 * h * w;
-    if (fmt == CAE_FMT_U8_HWC)
-        hipLaunchKernelGGL(u8hwc_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint8_t *)tiles,
-                           (float *)m->ws[0], n, h, w, m->c_org, p0);
-    else
-        hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)tiles,
-                           (float *)m->ws[0], n, m->c_org, h * w, p0);
-    HIP_TRY(hipGetLastError());
+    if (!first_fused) {
+        const size_t tot = (size_t)n * p0 * h * w;
+        if (fmt == CAE_FMT_U8_HWC)
+            hipLaunchKernelGGL(u8hwc_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint8_t *)tiles,
+                               (float *)m->ws[0], n, h, w, m->c_org, p0);
+        else
+            hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)tiles,
+                               (float *)m->ws[0], n, m->c_org, h * w, p0);
+        HIP_TRY(hipGetLastError());
+    }
     prof.end();
 
     const float *cur = (const float *)m->ws[0];
@@ -414,7 +517,13 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
         a.tiles_y = (a.OH + 7) / 8;
         a.outfmt = last ? OUT_NCHW : OUT_C8;
         prof.begin();
-        if ((rc = launch_conv(m->ks, l.ct, l.gdn, a, st))) return rc;
+        if (i == 0 && first_fused) {
+            FirstArgs f{tiles, fmt == CAE_FMT_U8_HWC ? 1 : 0, l.cin};
+            a.wp = l.wp_edge;
+            if ((rc = launch_first(m->ks, l.ct, l.gdn, a, f, st))) return rc;
+        } else {
+            if ((rc = launch_conv(m->ks, l.ct, l.gdn, a, st))) return rc;
+        }
         prof.end();
         cur = (const float *)a.out;
         cur_planes = l.ct * 4;
@@ -485,7 +594,14 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
         a.tiles_y = (ch + 3) / 4;
         a.outfmt = last ? (fmt == CAE_FMT_U8_HWC ? OUT_U8HWC : OUT_NCHW) : OUT_C8;
         prof.begin();
-        if ((rc = launch_deconv(m->ks, l.ct, l.gdn, a, st))) return rc;
+        if (last && l.wp_edge) {
+            a.wp = l.wp_edge;
+            a.cci = (l.cin + 15) / 16;
+            a.tiles_x = (cw + 15) / 16;
+            if ((rc = launch_last(m->ks, a, st))) return rc;
+        } else {
+            if ((rc = launch_deconv(m->ks, l.ct, l.gdn, a, st))) return rc;
+        }
         prof.end();
         if (!last && bridges && bridges[i]) {
             const size_t t2 = (size_t)n * l.cout * a.OH * a.OW;

@@ -19,6 +19,7 @@ struct Layer {
     float *bias = nullptr;  // [ct*32] (device) or null
     float *gp = nullptr;    // packed gamma (device)
     float *beta = nullptr;  // [ct*32] (device)
+    float *wp_edge = nullptr;  // packed weights of the specialised first-conv / last-deconv kernel, or null
 };
 
 // Integer tables of the factorized entropy model + per-row encoder constants.

@@ -448,6 +448,168 @@ __global__ void __launch_bounds__(NW * 64, CT >= 6 ? 1 : 2) deconv_s2_kernel(con
 }
 
 // =================================================================================================
+// First analysis layer: few input channels (Cin <= 4, e.g. RGB) read straight from the caller's
+// tensor -- uint8 HWC (fusing the x/255 of codec.encode, _autoencoders.py:542-545) or float NCHW.
+//   K is packed as (tap, 4 channels): 2*KS*KS MFMA k-steps instead of the 4*KS*KS a padded
+//   8-channel chunk would cost.  The whole halo ((2TY+KS-2) x (2TX+KS-2) pixels x float4) and all
+//   packed weights stay in LDS for the block; gamma pieces stream through a double buffer.
+//   packed weights: [tap][ct][lane][2]: W(cout = 32ct + (lane&31), ch = 2j + (lane>>5), tap), j = 0,1
+// =================================================================================================
+struct FirstArgs {
+    const void *in;  // (N,H,W,C) uint8  |  (N,C,H,W) float
+    int in_is_u8;
+    int cin;
+};
+
+template <int KS, int CT, int NW, bool GDN>
+__global__ void __launch_bounds__(NW * 64, 2) conv_first_kernel(const LayerArgs p, const FirstArgs f) {
+    constexpr int PAD = KS / 2;
+    constexpr int TX = 16, TY = 2 * NW;
+    constexpr int WH = 2 * TX + KS - 2, HH = 2 * TY + KS - 2;
+    constexpr int W_BYTES = KS * KS * CT * 512;
+    constexpr int G_BYTES = GDN ? CT * 4096 : 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *gbuf = smem;                       // 2 * G_BYTES (double-buffered gamma pieces)
+    char *wbuf = smem + 2 * G_BYTES;         // W_BYTES
+    char *hbuf = wbuf + W_BYTES;             // HALO_BYTES
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n = bid / p.tiles_y;
+    const int oy0 = ty * TY, ox0 = tx * TX;
+
+    int sc = 0;
+    if (GDN) issue_gamma0<CT, NW>(p, gbuf, wave, lane);
+    // weights: plain copy of W_BYTES
+    for (int i = threadIdx.x; i < W_BYTES / 16; i += NW * 64)
+        *(f32x4 *)(wbuf + i * 16) = *(const f32x4 *)((const char *)p.wp + i * 16);
+    // halo: one pixel (float4, channels >= cin are zero) per thread-iteration
+    for (int i = threadIdx.x; i < HH * WH; i += NW * 64) {
+        const int r = i / WH, x = i - r * WH;
+        const int iy = reflect_idx(2 * oy0 - PAD + r, p.H), ix = reflect_idx(2 * ox0 - PAD + x, p.W);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (f.in_is_u8) {
+            const uint8_t *src = (const uint8_t *)f.in + (((size_t)n * p.H + iy) * p.W + ix) * f.cin;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < f.cin) v[c] = (float)src[c] / 255.0f;
+        } else {
+            const float *src = (const float *)f.in + (size_t)n * f.cin * p.H * p.W + (size_t)iy * p.W + ix;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < f.cin) v[c] = src[(size_t)c * p.H * p.W];
+        }
+        *(f32x4 *)(hbuf + i * 16) = v;
+    }
+    __syncthreads();
+
+    f32x16 acc[CT];
+    init_acc<CT>(acc, p.bias, h, 0.0f);
+    const int wrow = 2 * wave + (m >> 4);
+    const char *hb = hbuf + ((2 * wrow) * WH + 2 * (m & 15)) * 16;
+    const char *wb = wbuf + lane * 8;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const f32x4 v = *(const f32x4 *)(hb + (ky * WH + kx) * 16);
+            const float b0 = h ? v[1] : v[0];
+            const float b1 = h ? v[3] : v[2];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 a = *(const f32x2 *)(wb + ((ky * KS + kx) * CT + ct) * 512);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b0, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b1, acc[ct], 0, 0, 0);
+            }
+        }
+
+    if constexpr (GDN) {
+        gdn_stages<CT, NW, false, G_BYTES>(acc, p, gbuf, sc, wave, lane, [](char *) {});
+    }
+    const int oy = oy0 + wrow, ox = ox0 + (m & 15);
+    store_tiles<CT>(acc, p, n, oy, ox, h, oy < p.OH && ox < p.OW);
+}
+
+// =================================================================================================
+// Last synthesis layer: few output channels (Cout <= 4, e.g. RGB), no IGDN.
+//   Gather form on v_mfma_f32_16x16x4_f32: D rows = (cout c, phase p) = 4c + p (p = 2 py + px),
+//   D cols = 16 input pixels of one row, K = (neighbour (d, dx), cin):
+//     out[2i+py][2j+px][c] = sum_{d,dx,cin} in[i-d][j-dx][cin] * W[cin][c][2d+py+P][2dx+px+P]
+//   (taps outside the kernel are zero rows of the packed matrix).  All packed weights live in LDS;
+//   the activations stream from HBM/L2 straight into registers (each lane 16 B = 4 channels).
+//   packed weights: [nbr][q][lane][4]: A(row = lane&15, k = cin 16q + 4(lane>>4) + s), s = 0..3
+// =================================================================================================
+template <int KS, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) deconv_last_kernel(const LayerArgs p) {
+    constexpr int P = KS / 2;
+    constexpr int DLO = -((P + 1) / 2), DHI = (KS - 1 - P) / 2;
+    constexpr int NB = DHI - DLO + 1;  // neighbours per axis
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, col = lane & 15;
+    const int nq = p.cci;  // number of 16-channel groups
+    const int w_bytes = NB * NB * nq * 1024;
+    for (int i = threadIdx.x; i < w_bytes / 16; i += NW * 64)
+        *(f32x4 *)(smem + i * 16) = *(const f32x4 *)((const char *)p.wp + i * 16);
+    __syncthreads();
+
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n = bid / p.tiles_y;
+    const int iy = ty * NW + wave, ix = tx * 16 + col;
+    const size_t plane_sz = (size_t)p.H * p.W * 8;
+    const float *in_n = p.in + (size_t)n * p.in_planes * plane_sz;
+
+    f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (p.bias && g < p.cout) ? p.bias[g] : 0.0f;
+
+    if (iy < p.H) {  // wave-uniform
+#pragma unroll
+        for (int nd = 0; nd < NB; ++nd)
+#pragma unroll
+            for (int ndx = 0; ndx < NB; ++ndx) {
+                const int sy = iy - (DLO + nd), sx = ix - (DLO + ndx);
+                const bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+                // lane group g reads channels 16q + 4g .. +3  = plane 2q + (g>>1), byte offset (g&1)*16
+                const float *src = ok ? in_n + ((size_t)sy * p.W + sx) * 8 + (g >> 1) * plane_sz + (g & 1) * 4
+                                      : p.zero;
+                const size_t qstride = ok ? 2 * plane_sz : 0;
+                const char *wb = smem + ((nd * NB + ndx) * nq) * 1024 + lane * 16;
+                for (int q = 0; q < nq; ++q) {
+                    const f32x4 b = *(const f32x4 *)(src + q * qstride);
+                    const f32x4 a = *(const f32x4 *)(wb + q * 1024);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+                }
+            }
+    }
+    // lane (col, g = cout): acc[r] = output phase r = 2 py + px of input pixel (iy, ix)
+    if (iy < p.H && ix < p.W && g < p.cout) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oy = 2 * iy + (r >> 1), ox = 2 * ix + (r & 1);
+            if (p.outfmt == OUT_U8HWC) {
+                float v = acc[r] * 255.0f;
+                v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+                ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + g] = (uint8_t)v;
+            } else {
+                ((float *)p.out)[(((size_t)n * p.cout + g) * p.OH + oy) * p.OW + ox] = acc[r];
+            }
+        }
+    }
+}
+
+// =================================================================================================
 // Stand-alone GDN / IGDN on a C8 tensor (nn.Module surface for compressai.layers.GDN)
 //   block = NW waves, each wave 32 consecutive pixels of the flattened H*W plane.
 // =================================================================================================
