@@ -211,7 +211,7 @@ template <int KS, int CT, bool GDN>
 static int launch_first_t(const LayerArgs &a, const FirstArgs &f, hipStream_t st) {
     constexpr int NW = 4;
     constexpr int WH = 2 * 16 + KS - 2, HH = 4 * NW + KS - 2;
-    constexpr int LDS = 2 * (GDN ? CT * 4096 : 0) + KS * KS * CT * 512 + ((HH * WH * 16 + 1023) / 1024) * 1024;
+    constexpr int LDS = 2 * (GDN ? CT * 4096 : 0) + KS * KS * CT * 512 + ((HH * WH * 16 + 1023) / 1024) * 1024 + 1024;
     auto kern = conv_first_kernel<KS, CT, NW, GDN>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -229,7 +229,8 @@ static int launch_last_t(const LayerArgs &a, hipStream_t st) {
     constexpr int NW = 4;
     constexpr int P = KS / 2;
     constexpr int NB = (KS - 1 - P) / 2 + (P + 1) / 2 + 1;
-    const int lds = NB * NB * a.cci * 1024;
+    constexpr int HALO_INSTR = (4 * (NW + NB - 1) * (64 + NB - 1) + 63) / 64;
+    const int lds = 2 * HALO_INSTR * 1024 + NB * NB * a.cci * 1024;
     auto kern = deconv_last_kernel<KS, NW>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
@@ -597,7 +598,7 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
         if (last && l.wp_edge) {
             a.wp = l.wp_edge;
             a.cci = (l.cin + 15) / 16;
-            a.tiles_x = (cw + 15) / 16;
+            a.tiles_x = (cw + 63) / 64;
             if ((rc = launch_last(m->ks, a, st))) return rc;
         } else {
             if ((rc = launch_deconv(m->ks, l.ct, l.gdn, a, st))) return rc;
@@ -649,6 +650,22 @@ int cae_gdn_forward(cae_model_t *mm, int track, int index, const float *x, int n
     a.cout = l.cout;
     a.outfmt = OUT_NCHW;
     return launch_gdn(l.ct, track == CAE_SYNTHESIS, a, st);
+}
+
+int cae_tile_sse(const uint8_t *a, const uint8_t *b, int n, size_t elems, double *sse, void *stream) {
+    if (!a || !b || !sse) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || elems < 1) return fail(CAE_ERR_ARG, "bad shape");
+    if (((uintptr_t)a | (uintptr_t)b) & 15 || (elems & 15)) return fail(CAE_ERR_ARG, "tiles must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    // the float64 output doubles as the exact integer accumulator (same 8-byte cells)
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(sse);
+    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)n * 8, st));
+    const unsigned bx = (unsigned)std::min<size_t>(std::max<size_t>(elems / 16 / 256, 1), 64);
+    hipLaunchKernelGGL(tile_sse_kernel, dim3(bx, n), dim3(256), 0, st, a, b, elems, acc);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(u64_to_f64_kernel, dim3((n + 255) / 256), dim3(256), 0, st, acc, sse, n);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
 }
 
 int cae_model_set_profiling(cae_model_t *mm, int enable) {

@@ -471,7 +471,8 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_first_kernel(const LayerArgs 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *gbuf = smem;                       // 2 * G_BYTES (double-buffered gamma pieces)
     char *wbuf = smem + 2 * G_BYTES;         // W_BYTES
-    char *hbuf = wbuf + W_BYTES;             // HALO_BYTES
+    char *hbuf = wbuf + W_BYTES;             // halo: HH*WH float4, then a 256-entry table of x/255.0f
+    float *lut = (float *)(hbuf + ((HH * WH * 16 + 1023) / 1024) * 1024);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -488,6 +489,11 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_first_kernel(const LayerArgs 
     // weights: plain copy of W_BYTES
     for (int i = threadIdx.x; i < W_BYTES / 16; i += NW * 64)
         *(f32x4 *)(wbuf + i * 16) = *(const f32x4 *)((const char *)p.wp + i * 16);
+    // uint8 -> float by table: the 256 possible results of the true division torch performs
+    if (f.in_is_u8) {
+        for (int i = threadIdx.x; i < 256; i += NW * 64) lut[i] = (float)i / 255.0f;
+        __syncthreads();
+    }
     // halo: one pixel (float4, channels >= cin are zero) per thread-iteration
     for (int i = threadIdx.x; i < HH * WH; i += NW * 64) {
         const int r = i / WH, x = i - r * WH;
@@ -497,7 +503,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_first_kernel(const LayerArgs 
             const uint8_t *src = (const uint8_t *)f.in + (((size_t)n * p.H + iy) * p.W + ix) * f.cin;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (c < f.cin) v[c] = (float)src[c] / 255.0f;
+                if (c < f.cin) v[c] = lut[src[c]];
         } else {
             const float *src = (const float *)f.in + (size_t)n * f.cin * p.H * p.W + (size_t)iy * p.W + ix;
 #pragma unroll
@@ -549,61 +555,104 @@ template <int KS, int NW>
 __global__ void __launch_bounds__(NW * 64, 2) deconv_last_kernel(const LayerArgs p) {
     constexpr int P = KS / 2;
     constexpr int DLO = -((P + 1) / 2), DHI = (KS - 1 - P) / 2;
-    constexpr int NB = DHI - DLO + 1;  // neighbours per axis
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NB = DHI - DLO + 1;        // neighbours per axis
+    constexpr int TXC = 64;                  // input columns per block (4 MFMA column tiles per wave)
+    constexpr int WH = TXC + NB - 1, HR = NW + NB - 1;
+    constexpr int PLANE_PIECES = HR * WH;    // 16-byte pieces per 4-channel group
+    constexpr int HALO_PIECES = 4 * PLANE_PIECES;
+    constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;
+    constexpr int STAGE_BYTES = HALO_INSTR * 1024;
+    constexpr int MAXP = (HALO_INSTR + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][weights]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, col = lane & 15;
     const int nq = p.cci;  // number of 16-channel groups
-    const int w_bytes = NB * NB * nq * 1024;
-    for (int i = threadIdx.x; i < w_bytes / 16; i += NW * 64)
-        *(f32x4 *)(smem + i * 16) = *(const f32x4 *)((const char *)p.wp + i * 16);
-    __syncthreads();
+    char *wbuf = smem + 2 * STAGE_BYTES;
 
     int bid = blockIdx.x;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
     const int n = bid / p.tiles_y;
-    const int iy = ty * NW + wave, ix = tx * 16 + col;
+    const int iy0 = ty * NW, ix0 = tx * TXC;
     const size_t plane_sz = (size_t)p.H * p.W * 8;
     const float *in_n = p.in + (size_t)n * p.in_planes * plane_sz;
 
-    f32x4 acc;
+    // halo pieces of this lane: LDS image [g'][row][x] of 16-byte pieces (4 channels each)
+    long hsrc[MAXP];  // float offset inside the 16-channel group, or -1 (outside the image)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = (p.bias && g < p.cout) ? p.bias[g] : 0.0f;
+    for (int i = 0; i < MAXP; ++i) {
+        int pc = (wave + i * NW) * 64 + lane;
+        pc = pc < HALO_PIECES ? pc : HALO_PIECES - 1;
+        const int gg = pc / PLANE_PIECES;
+        const int rem = pc - gg * PLANE_PIECES;
+        const int r = rem / WH, x = rem - r * WH;
+        const int sy = iy0 - DHI + r, sx = ix0 - DHI + x;
+        const bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+        hsrc[i] = ok ? (long)(gg >> 1) * (long)plane_sz + ((long)sy * p.W + sx) * 8 + (gg & 1) * 4 : -1;
+    }
+    auto issue = [&](int q, char *buf) {
+        const float *base = in_n + (size_t)(2 * q) * plane_sz;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int j = wave + i * NW;
+            if (j < HALO_INSTR) glds16(hsrc[i] >= 0 ? (const void *)(base + hsrc[i]) : (const void *)p.zero, buf + j * 1024);
+        }
+    };
 
-    if (iy < p.H) {  // wave-uniform
+    issue(0, smem);
+    const int w_bytes = NB * NB * nq * 1024;
+    for (int i = threadIdx.x; i < w_bytes / 16; i += NW * 64)
+        *(f32x4 *)(wbuf + i * 16) = *(const f32x4 *)((const char *)p.wp + i * 16);
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = (p.bias && g < p.cout) ? p.bias[g] : 0.0f;
+
+    for (int q = 0; q < nq; ++q) {
+        wait_vm0();
+        __syncthreads();
+        char *cur = smem + (q & 1) * STAGE_BYTES;
+        if (q + 1 < nq) issue(q + 1, smem + ((q + 1) & 1) * STAGE_BYTES);
 #pragma unroll
         for (int nd = 0; nd < NB; ++nd)
 #pragma unroll
             for (int ndx = 0; ndx < NB; ++ndx) {
-                const int sy = iy - (DLO + nd), sx = ix - (DLO + ndx);
-                const bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
-                // lane group g reads channels 16q + 4g .. +3  = plane 2q + (g>>1), byte offset (g&1)*16
-                const float *src = ok ? in_n + ((size_t)sy * p.W + sx) * 8 + (g >> 1) * plane_sz + (g & 1) * 4
-                                      : p.zero;
-                const size_t qstride = ok ? 2 * plane_sz : 0;
-                const char *wb = smem + ((nd * NB + ndx) * nq) * 1024 + lane * 16;
-                for (int q = 0; q < nq; ++q) {
-                    const f32x4 b = *(const f32x4 *)(src + q * qstride);
-                    const f32x4 a = *(const f32x4 *)(wb + q * 1024);
+                // in[i - d][j - dx], d = DLO + nd: halo row wave - d + DHI, halo column col - dx + DHI
+                const int hr = wave - (DLO + nd) + DHI;
+                const int hx = col - (DLO + ndx) + DHI;
+                const f32x4 a = *(const f32x4 *)(wbuf + ((nd * NB + ndx) * nq + q) * 1024 + lane * 16);
+                const char *hb = cur + ((g * HR + hr) * WH + hx) * 16;
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 b = *(const f32x4 *)(hb + t * 256);
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s2], b[s2], acc[t], 0, 0, 0);
                 }
             }
     }
-    // lane (col, g = cout): acc[r] = output phase r = 2 py + px of input pixel (iy, ix)
-    if (iy < p.H && ix < p.W && g < p.cout) {
+    // lane (col, g = cout): acc[t][r] = output phase r = 2 py + px of input pixel (iy, ix0 + 16 t + col)
+    const int iy = iy0 + wave;
+    if (iy < p.H && g < p.cout) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int oy = 2 * iy + (r >> 1), ox = 2 * ix + (r & 1);
-            if (p.outfmt == OUT_U8HWC) {
-                float v = acc[r] * 255.0f;
-                v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
-                ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + g] = (uint8_t)v;
-            } else {
-                ((float *)p.out)[(((size_t)n * p.cout + g) * p.OH + oy) * p.OW + ox] = acc[r];
+        for (int t = 0; t < 4; ++t) {
+            const int ix = ix0 + 16 * t + col;
+            if (ix < p.W) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int oy = 2 * iy + (r >> 1), ox = 2 * ix + (r & 1);
+                    if (p.outfmt == OUT_U8HWC) {
+                        float v = acc[t][r] * 255.0f;
+                        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+                        ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + g] = (uint8_t)v;
+                    } else {
+                        ((float *)p.out)[(((size_t)n * p.cout + g) * p.OH + oy) * p.OW + ox] = acc[t][r];
+                    }
+                }
             }
         }
     }
@@ -713,6 +762,40 @@ __global__ void dequantize_kernel(const int32_t *sym, const float *medians, floa
         const int c = (int)((i / HW) % C);
         y[i] = (float)sym[i] + medians[c];
     }
+}
+
+// per-tile sum of squared byte differences; one block row per tile, exact integer partial sums
+__global__ void tile_sse_kernel(const uint8_t *a, const uint8_t *b, size_t elems, unsigned long long *out) {
+    const int tile = blockIdx.y;
+    const uint8_t *pa = a + (size_t)tile * elems, *pb = b + (size_t)tile * elems;
+    unsigned long long acc = 0;
+    const size_t nvec = elems / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 va = ((const uint4 *)pa)[i], vb = ((const uint4 *)pb)[i];
+        const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+        unsigned s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = (int)((wa[k] >> (8 * j)) & 255u) - (int)((wb[k] >> (8 * j)) & 255u);
+                s += (unsigned)(d * d);
+            }
+        acc += s;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = nvec * 16 + threadIdx.x; i < elems; i += blockDim.x) {
+            const int d = (int)pa[i] - (int)pb[i];
+            acc += (unsigned)(d * d);
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out + tile, acc);
+}
+
+__global__ void u64_to_f64_kernel(const unsigned long long *in, double *out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
 }
 
 }  // namespace cae

@@ -113,9 +113,13 @@ class SlideCoder:
     @torch.no_grad()
     def tile_sse(self, rec: torch.Tensor, tiles: torch.Tensor) -> torch.Tensor:
         """per-tile sum of squared error of two (n,h,w,c) uint8 batches -> (n,) float64 on the GPU."""
+        from . import _lib
         n = tiles.shape[0]
-        d = rec.reshape(n, -1).to(torch.int16) - tiles.reshape(n, -1).to(torch.int16)
-        return (d.to(torch.int32) * d.to(torch.int32)).sum(dim=1, dtype=torch.int64).to(torch.float64)
+        rec, tiles = rec.contiguous(), tiles.contiguous()
+        out = torch.empty(n, dtype=torch.float64, device=tiles.device)
+        _lib.check(_lib.lib().cae_tile_sse(rec.data_ptr(), tiles.data_ptr(), n, tiles[0].numel(), out.data_ptr(),
+                                           _lib.stream_ptr()))
+        return out
 
     @torch.no_grad()
     def roundtrip(self, tiles_dev: torch.Tensor) -> Tuple[List[bytes], torch.Tensor, torch.Tensor]:
@@ -181,7 +185,12 @@ class SlideCoder:
         def stage_d(k, payloads, back):
             t = batches[k]
             n, h, w, c = t.shape
-            sym = back.to(dev, non_blocking=True)
+            with torch.cuda.stream(copy):  # H2D beside the kernels of the main stream
+                sym = back.to(dev, non_blocking=True)
+                up = torch.cuda.Event()
+                up.record(copy)
+            main.wait_event(up)
+            sym.record_stream(main)
             lh, lw = h // 2 ** self.level, w // 2 ** self.level
             y_q = self.eb.dequantize_symbols(sym.reshape(n, self.eb.channels, lh, lw))
             rec = self.dec.forward_u8(y_q)

@@ -99,6 +99,11 @@ int cae_gdn_forward(cae_model_t *m, int track, int index, const float *x_dev, in
 int cae_quantize(cae_model_t *m, const float *latents_dev, int n, int hw, int32_t *symbols_dev, void *stream);
 int cae_dequantize(cae_model_t *m, const int32_t *symbols_dev, int n, int hw, float *latents_dev, void *stream);
 
+/* Per-tile sum of squared differences of two (n, elems) uint8 batches -> sse_dev[n] (float64).
+ * The distortion half of the per-tile statistics record the slide driver all-gathers (the
+ * reference's harness computes MSE/PSNR on the host, test_cae.py:55-68). */
+int cae_tile_sse(const uint8_t *a_dev, const uint8_t *b_dev, int n, size_t elems, double *sse_dev, void *stream);
+
 /* ---- measurement ------------------------------------------------------------------------
  * With profiling on, cae_analysis / cae_synthesis bracket every kernel they launch with HIP
  * events on the caller's stream.  cae_model_get_profile synchronises those events and ADDS the

@@ -229,3 +229,28 @@ def test_error_behaviour(cae):
         model['fact_ent'].module.compress(torch.rand(1, 7, 4, 4).cuda())
     with pytest.raises(cae.CaeError):
         model['fact_ent'].module.decompress([b'\x00\x01'], (4, 4))  # truncated stream
+
+
+def test_tile_sse_exact(cae):
+    from cnn_autoencoder_amd import slide, synth
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (3, 48, 80, 3), dtype=np.uint8)
+    b = rng.integers(0, 256, (3, 48, 80, 3), dtype=np.uint8)
+    state = synth.synthetic_state(dict(synth.CANONICAL, channels_net=8, channels_bn=16, compression_level=2), seed=1)
+    coder = slide.SlideCoder(cae.ConvolutionalAutoencoder(checkpoint=state))
+    got = coder.tile_sse(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    want = ((a.astype(np.int64) - b.astype(np.int64)) ** 2).reshape(3, -1).sum(axis=1)
+    assert np.array_equal(got, want.astype(np.float64))
+
+
+def test_pipelined_run_equals_simple_roundtrip(cae):
+    from cnn_autoencoder_amd import slide, synth
+    state = synth.synthetic_state(dict(synth.CANONICAL, channels_net=32, channels_bn=48), seed=2)
+    coder = slide.SlideCoder(cae.ConvolutionalAutoencoder(checkpoint=state))
+    batches = [torch.from_numpy(synth.uniform_tiles(3, 64, 96, seed=s)).cuda() for s in (1, 2, 3)]
+    stats, payloads = coder.run(batches, keep_payloads=True)
+    ref = [coder.roundtrip(b) for b in batches]
+    assert payloads == [r[0] for r in ref]
+    assert torch.equal(stats, torch.cat([r[2] for r in ref]))
+    s = slide.slide_summary(slide.gather_stats(stats), 64 * 96)
+    assert s['tiles'] == 9 and s['bpp'] > 0 and np.isfinite(s['psnr'])
