@@ -14,7 +14,8 @@ import threading
 import torch  # noqa: F401  (loads torch's libamdhip64 first so both share one HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcae_hip.so')
+# CAE_LIB: alternative build of the same library (kernel A/B experiments); never a different implementation
+LIB_PATH = os.environ.get('CAE_LIB') or os.path.join(_HERE, 'libcae_hip.so')
 _lock = threading.Lock()
 _lib = None
 

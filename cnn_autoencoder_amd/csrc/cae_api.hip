@@ -166,14 +166,24 @@ Model::~Model() {
 }
 
 // ---- kernel dispatch ---------------------------------------------------------------------------
+#ifndef CAE_CONV_NW
+#define CAE_CONV_NW 4
+#endif
+#ifndef CAE_DECONV_NW
+#define CAE_DECONV_NW 4
+#endif
 template <int KS, int CT, bool GDN>
 static int launch_conv_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = 4;
+    constexpr int NW = CAE_CONV_NW;
     constexpr int WH = 2 * 16 + KS - 2;
     constexpr int HALO_INSTR = (2 * NW * WH * 2 + 63) / 64;
     constexpr int CONV_STAGE = KS * CT * 1024 + HALO_INSTR * 1024;
     constexpr int G_BYTES = GDN ? CT * 4096 : 0;
+#ifdef CAE_EXP_1BLOCK
+    constexpr int LDS = 96 * 1024;
+#else
     constexpr int LDS = 2 * (CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES);
+#endif
     auto kern = conv_s2_kernel<KS, CT, NW, GDN>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -188,7 +198,7 @@ static int launch_conv_t(const LayerArgs &a, hipStream_t st) {
 
 template <int KS, int CT, bool GDN>
 static int launch_deconv_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = 4;
+    constexpr int NW = CAE_DECONV_NW;
     constexpr int P = KS / 2;
     constexpr int WH = 32 + (KS - 1 - P) / 2 + (P + 1) / 2;
     constexpr int HALO_INSTR = (NW * WH * 2 + 63) / 64;
@@ -515,7 +525,7 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
         a.out_planes = l.ct * 4;
         a.cout = l.cout;
         a.tiles_x = (a.OW + 15) / 16;
-        a.tiles_y = (a.OH + 7) / 8;
+        a.tiles_y = (a.OH + 2 * CAE_CONV_NW - 1) / (2 * CAE_CONV_NW);
         a.outfmt = last ? OUT_NCHW : OUT_C8;
         prof.begin();
         if (i == 0 && first_fused) {
@@ -592,7 +602,7 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
         a.out_planes = l.ct * 4;
         a.cout = l.cout;
         a.tiles_x = (cw + 31) / 32;
-        a.tiles_y = (ch + 3) / 4;
+        a.tiles_y = (ch + CAE_DECONV_NW - 1) / CAE_DECONV_NW;
         a.outfmt = last ? (fmt == CAE_FMT_U8_HWC ? OUT_U8HWC : OUT_NCHW) : OUT_C8;
         prof.begin();
         if (last && l.wp_edge) {

@@ -26,6 +26,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 
 namespace cae {
 
@@ -50,6 +52,16 @@ struct LayerArgs {
     int tiles_x, tiles_y;
     int outfmt;
 };
+
+// compile-time unrolled loop: f(std::integral_constant<int, I>{}) for I = 0..N-1
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl<N>(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     i = i < 0 ? -i : i;
@@ -95,6 +107,10 @@ __device__ __forceinline__ void gdn_stages(f32x16 (&y)[CT], const LayerArgs &p, 
         __syncthreads();
         char *cur = smem + (sc & 1) * STAGE_BYTES;
         char *nxt = smem + ((sc + 1) & 1) * STAGE_BYTES;
+        const char *gb = cur + lane * 16;
+        f32x4 g_cur[CT];
+#pragma unroll
+        for (int co = 0; co < CT; ++co) g_cur[co] = *(const f32x4 *)(gb + (co * 4) * 1024);
         if (jt + 1 < CT) {
             const char *src = (const char *)p.gp + (size_t)(jt + 1) * G_BYTES;
 #pragma unroll
@@ -105,19 +121,25 @@ __device__ __forceinline__ void gdn_stages(f32x16 (&y)[CT], const LayerArgs &p, 
         } else {
             tail(nxt);
         }
-        const char *gb = cur + lane * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 g[CT];
+            f32x4 g_nxt[CT];
+            if (q + 1 < 4) {
 #pragma unroll
-            for (int co = 0; co < CT; ++co) g[co] = *(const f32x4 *)(gb + (co * 4 + q) * 1024);
+                for (int co = 0; co < CT; ++co) g_nxt[co] = *(const f32x4 *)(gb + (co * 4 + q + 1) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const float v = y[jt][4 * q + jj];
                 const float sq = v * v;
 #pragma unroll
                 for (int co = 0; co < CT; ++co)
-                    nrm[co] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[co][jj], sq, nrm[co], 0, 0, 0);
+                    nrm[co] = __builtin_amdgcn_mfma_f32_32x32x2f32(g_cur[co][jj], sq, nrm[co], 0, 0, 0);
+            }
+            if (q + 1 < 4) {
+#pragma unroll
+                for (int co = 0; co < CT; ++co) g_cur[co] = g_nxt[co];
             }
         }
         ++sc;
@@ -191,8 +213,11 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const Layer
 //   tile   = (2 NW) x 16 output pixels, all CT*32 output channels
 //   stage  = (8-channel chunk c, kernel row ky): KS taps x CT KiB of weights + TY halo rows
 // =================================================================================================
+#ifndef CAE_CONV_WAVES
+#define CAE_CONV_WAVES 2
+#endif
 template <int KS, int CT, int NW, bool GDN>
-__global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : 2) conv_s2_kernel(const LayerArgs p) {
+__global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : (CT <= 4 ? CAE_CONV_WAVES : 2)) conv_s2_kernel(const LayerArgs p) {
     constexpr int PAD = KS / 2;
     constexpr int TX = 16, TY = 2 * NW;
     constexpr int WH = 2 * TX + KS - 2;  // halo columns
@@ -217,8 +242,10 @@ __global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : 2) conv_s2_ker
     const int n = bid / p.tiles_y;
     const int oy0 = ty * TY, ox0 = tx * TX;
 
-    // per-lane halo pieces: piece = (row r, column x, half) -> LDS offset 16*piece
-    int hrow[MAXP], hxoff[MAXP];
+    // per-lane halo pieces: piece = (row r, column x, half) -> LDS offset 16*piece.  The byte offset
+    // of every piece inside one 8-channel plane is fixed per kernel row ky (reflect padding resolved
+    // here, once), so a stage's DMA is: scalar plane base + 32-bit lane offset.
+    unsigned hoff[MAXP][KS];
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         int pc = (wave + i * NW) * 64 + lane;
@@ -226,28 +253,29 @@ __global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : 2) conv_s2_ker
         const int r = pc / (2 * WH);
         const int rem = pc - r * (2 * WH);
         const int x = rem >> 1;
-        hrow[i] = 2 * (oy0 + r) - PAD;
-        hxoff[i] = reflect_idx(2 * ox0 - PAD + x, p.W) * 8 + (rem & 1) * 4;
+        const unsigned xo = (unsigned)reflect_idx(2 * ox0 - PAD + x, p.W) * 32u + (unsigned)(rem & 1) * 16u;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+            hoff[i][ky] = (unsigned)reflect_idx(2 * (oy0 + r) - PAD + ky, p.H) * (unsigned)p.W * 32u + xo;
     }
-    const size_t plane_sz = (size_t)p.H * p.W * 8;
-    const float *in_n = p.in + (size_t)n * p.in_planes * plane_sz;
+    const size_t plane_bytes = (size_t)p.H * p.W * 32;
+    const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
+    const unsigned woff = (unsigned)lane * 16u;
 
-    auto issue_stage = [&](int s, char *buf) {
-        const int c = s / KS, ky = s - c * KS;
-        const char *wsrc = (const char *)p.wp + (size_t)s * W_BYTES;
+    // stage (c, ky): weights [c][ky] (KS*CT KiB, contiguous) + the TY halo rows of plane c
+    auto issue_stage = [&](int c, auto ky_tag, char *buf) {
+        constexpr int ky = decltype(ky_tag)::value;
+        const char *wsrc = (const char *)p.wp + (size_t)(c * KS + ky) * W_BYTES;
 #pragma unroll
         for (int i = 0; i < (W_INSTR + NW - 1) / NW; ++i) {
             const int j = wave + i * NW;
-            if (j < W_INSTR) glds16(wsrc + j * 1024 + lane * 16, buf + j * 1024);
+            if (j < W_INSTR) glds16(wsrc + j * 1024 + woff, buf + j * 1024);
         }
-        const float *plane = in_n + (size_t)c * plane_sz;
+        const char *plane = in_n + (size_t)c * plane_bytes;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             const int j = wave + i * NW;
-            if (j < HALO_INSTR) {
-                const int iy = reflect_idx(hrow[i] + ky, p.H);
-                glds16(plane + (size_t)iy * p.W * 8 + hxoff[i], buf + W_BYTES + j * 1024);
-            }
+            if (j < HALO_INSTR) glds16(plane + hoff[i][ky], buf + W_BYTES + j * 1024);
         }
     };
 
@@ -256,35 +284,63 @@ __global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : 2) conv_s2_ker
 
     const int wrow = 2 * wave + (m >> 4);
     const int b_off = W_BYTES + ((wrow * WH + 2 * (m & 15)) * 8 + 4 * h) * 4;
-    const int NS = p.cci * KS;
     int sc = 0;
 
-    issue_stage(0, smem);
-    for (int s = 0; s < NS; ++s) {
-        wait_vm0();
-        __syncthreads();
-        char *cur = smem + (sc & 1) * STAGE_BYTES;
-        char *nxt = smem + ((sc + 1) & 1) * STAGE_BYTES;
-        if (s + 1 < NS) {
-            issue_stage(s + 1, nxt);
-        } else if (GDN) {
-            issue_gamma0<CT, NW>(p, nxt, wave, lane);
-        }
-        const char *wb = cur + lane * 16;
-        const char *hb = cur + b_off;
+    issue_stage(0, std::integral_constant<int, 0>{}, smem);
+    for (int c = 0; c < p.cci; ++c) {
+        static_for<KS>([&](auto ky_tag) {
+            constexpr int ky = decltype(ky_tag)::value;
+#if defined(CAE_EXP_NOWAIT)
+            __builtin_amdgcn_s_barrier();
+#elif !defined(CAE_EXP_NOBARRIER)
+            wait_vm0();
+            __syncthreads();
+#endif
+            char *cur = smem + (sc & 1) * STAGE_BYTES;
+            char *nxt = smem + ((sc + 1) & 1) * STAGE_BYTES;
+            const char *wb = cur + lane * 16;
+            const char *hb = cur + b_off;
+            // software pipeline inside the wave: operands of tap kx+1 are read while tap kx multiplies,
+            // and the next stage's LDS-DMA is issued under the latency of the first reads
+            f32x4 b_cur = *(const f32x4 *)(hb);
+            f32x4 a_cur[CT];
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-            const f32x4 b = *(const f32x4 *)(hb + kx * 32);
-            f32x4 a[CT];
+            for (int ct = 0; ct < CT; ++ct) a_cur[ct] = *(const f32x4 *)(wb + ct * 1024);
+#ifndef CAE_EXP_NODMA
+            if constexpr (ky + 1 < KS) {
+                issue_stage(c, std::integral_constant<int, ky + 1>{}, nxt);
+            } else {
+                if (c + 1 < p.cci) {
+                    issue_stage(c + 1, std::integral_constant<int, 0>{}, nxt);
+                } else if (GDN) {
+                    issue_gamma0<CT, NW>(p, nxt, wave, lane);
+                }
+            }
+#endif
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) a[ct] = *(const f32x4 *)(wb + (kx * CT + ct) * 1024);
+            for (int kx = 0; kx < KS; ++kx) {
+                f32x4 b_nxt = b_cur;
+                f32x4 a_nxt[CT];
+                if (kx + 1 < KS) {
+                    b_nxt = *(const f32x4 *)(hb + (kx + 1) * 32);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                    for (int ct = 0; ct < CT; ++ct)
+                        a_nxt[ct] = *(const f32x4 *)(wb + ((kx + 1) * CT + ct) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this tap's MFMAs
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct][j], b[j], acc[ct], 0, 0, 0);
-        }
-        ++sc;
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ct][j], b_cur[j], acc[ct], 0, 0, 0);
+                if (kx + 1 < KS) {
+                    b_cur = b_nxt;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) a_cur[ct] = a_nxt[ct];
+                }
+            }
+            ++sc;
+        });
     }
 
     if constexpr (GDN) {
@@ -362,6 +418,14 @@ __device__ __forceinline__ void deconv_phase(const LayerArgs &p, const float *in
         __syncthreads();
         char *cur = smem + (sc & 1) * STAGE_BYTES;
         char *nxt = smem + ((sc + 1) & 1) * STAGE_BYTES;
+        const char *wb = cur + lane * 16;
+        const char *hb = cur + b_off;
+        // kx = 2 dx + px + P  ->  px = parity(kx - P), dx = (kx - P - px) / 2;  B(kx) at hb - dx*32
+        constexpr int DX0 = (0 - P - ((0 + P) & 1)) / 2;
+        f32x4 b_cur = *(const f32x4 *)(hb - DX0 * 32);
+        f32x4 a_cur[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) a_cur[ct] = *(const f32x4 *)(wb + ct * 1024);
         if (s + 1 < NS) {
             deconv_issue<KS, CT, NW, IGDN, PY>(p, in_n, plane_sz, s + 1, nxt, hrow, hxoff, wave, lane);
         } else if (IGDN) {
@@ -369,26 +433,33 @@ __device__ __forceinline__ void deconv_phase(const LayerArgs &p, const float *in
         } else if (PY == 0) {
             deconv_issue<KS, CT, NW, IGDN, 1>(p, in_n, plane_sz, 0, nxt, hrow, hxoff, wave, lane);
         }
-        const char *wb = cur + lane * 16;
-        const char *hb = cur + b_off;
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
-            // kx = 2 dx + px + P  ->  px = parity(kx - P), dx = (kx - P - px) / 2
             const int px = (kx + P) & 1;
-            const int dx = (kx - P - px) / 2;
-            const f32x4 b = *(const f32x4 *)(hb - dx * 32);
-            f32x4 a[CT];
+            f32x4 b_nxt = b_cur;
+            f32x4 a_nxt[CT];
+            if (kx + 1 < KS) {
+                const int pxn = (kx + 1 + P) & 1;
+                const int dxn = (kx + 1 - P - pxn) / 2;
+                b_nxt = *(const f32x4 *)(hb - dxn * 32);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) a[ct] = *(const f32x4 *)(wb + (kx * CT + ct) * 1024);
+                for (int ct = 0; ct < CT; ++ct) a_nxt[ct] = *(const f32x4 *)(wb + ((kx + 1) * CT + ct) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this tap's MFMAs
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     if (px == 0)
-                        acc0[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct][j], b[j], acc0[ct], 0, 0, 0);
+                        acc0[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ct][j], b_cur[j], acc0[ct], 0, 0, 0);
                     else
-                        acc1[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct][j], b[j], acc1[ct], 0, 0, 0);
+                        acc1[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ct][j], b_cur[j], acc1[ct], 0, 0, 0);
                 }
+            if (kx + 1 < KS) {
+                b_cur = b_nxt;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) a_cur[ct] = a_nxt[ct];
+            }
         }
         ++sc;
     }
