@@ -161,7 +161,7 @@ class SlideCoder:
             sym = self.eb.quantize_symbols(y)
             n, C = sym.size(0), sym.size(1)
             hw = sym.numel() // (n * C)
-            pin = self._pin(('a', k & 1), (n, C, hw), torch.int32)
+            pin = self._pin(('a', k % 3), (n, C, hw), torch.int32)
             ready = torch.cuda.Event()
             ready.record(main)
             with torch.cuda.stream(copy):
@@ -177,7 +177,7 @@ class SlideCoder:
             t0 = time.perf_counter()
             payloads = self.eb.encode_symbols(pin.numpy(), self.coder_threads)
             t1 = time.perf_counter()
-            back = self._pin(('d', k & 1), pin.shape, torch.int32)  # decode straight into pinned memory
+            back = self._pin(('d', k % 3), pin.shape, torch.int32)  # decode straight into pinned memory
             self.eb.decode_symbols(payloads, hw, self.coder_threads, out=back.numpy())
             t2 = time.perf_counter()
             return payloads, back, t1 - t0, t2 - t1
@@ -198,19 +198,22 @@ class SlideCoder:
             return sse, [len(p) + 16 for p in payloads], h * w * c
 
         pending = []  # (sse tensor on GPU, nbytes list, samples)
+        DEPTH = 2  # analysis runs DEPTH batches ahead of synthesis: the host always has a batch to code
         with ThreadPoolExecutor(max_workers=1) as pool:
-            fut = pool.submit(host_code, *stage_a(0))
+            futs = {}
+            for k in range(min(DEPTH, K)):
+                futs[k] = pool.submit(host_code, *stage_a(k))
             for k in range(K):
-                nxt = pool.submit(host_code, *stage_a(k + 1)) if k + 1 < K else None
+                if k + DEPTH < K:
+                    futs[k + DEPTH] = pool.submit(host_code, *stage_a(k + DEPTH))
                 t0 = time.perf_counter()
-                payloads, back, te, td = fut.result()
+                payloads, back, te, td = futs.pop(k).result()
                 tm['wait_host'] += time.perf_counter() - t0
                 tm['host_encode'] += te
                 tm['host_decode'] += td
                 pending.append(stage_d(k, payloads, back))
                 if keep_payloads:
                     all_payloads.append(payloads)
-                fut = nxt
         for sse, nbytes, samples in pending:
             stats_parts.append(tile_stats(nbytes, sse.cpu().tolist(), samples))
         self.timers = tm
