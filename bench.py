@@ -99,11 +99,11 @@ def cpu_baseline(state, cfg, tiles, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=16)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--tile', type=int, default=1024)
     ap.add_argument('--batch', type=int, default=32, help='tiles per step per GPU')
-    ap.add_argument('--distinct', type=int, default=8, help='distinct synthetic tiles per rank (tiled to the batch)')
+    ap.add_argument('--distinct', type=int, default=4, help='distinct synthetic tiles per rank (tiled to the batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -182,6 +182,18 @@ def main():
             kernels.append((f'synthesis.{i} deconv{"+IGDN" if i < len(dec_fl) - 1 else ""}', f * B, dec_ms[1 + i] / max(dec_calls, 1)))
         dom = max(kernels, key=lambda k: k[2])
         achieved = dom[1] / (dom[2] * 1e-3) / 1e12
+        # HBM bytes per launch of the dominant kernel: measured offline by rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE passes of this same command (profiles/r01_hbm_traffic.json, FETCH_SIZE doubled per
+        # the gfx950 correction); only valid for the profiled shape (batch 32, 1024x1024 tiles)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['kernels']
+            key = {'analysis.1': 'conv_s2_kernel<3, 4, 4, true>@4194304',
+                   'synthesis.2': 'deconv_s2_kernel<3, 4, 4, true>@4194304'}.get(dom[0].split(' ')[0])
+            if key and B == 32 and H == 1024:
+                traffic = tj[key]['hbm_mb'] * 1e6
+        except Exception:
+            traffic = None
         gpu_ms = (sum(enc_ms) / max(enc_calls, 1), sum(dec_ms) / max(dec_calls, 1))
         line = {
             'metric': 'tiles/sec, compress+decompress round trip of 1024x1024x3 histology tiles',
@@ -202,7 +214,7 @@ def main():
                        'tile': H, 'sharding': f'contiguous tile blocks over {world} rank(s), 1 all_gather of stats'},
             'parity': {'bpp': summ['bpp'], 'psnr_db': summ['psnr'], 'tiles': summ['tiles']},
             'roofline': {'bound': 'mfma', 'kernel': dom[0], 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                          'ms_per_launch': dom[2], 'flop_per_launch': dom[1]},
             'kernels': [{'name': k[0], 'ms': k[2], 'tflops': k[1] / (k[2] * 1e-3) / 1e12 if k[2] > 0 else None}
                         for k in kernels],
