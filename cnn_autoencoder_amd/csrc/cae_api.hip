@@ -2,6 +2,7 @@
 #include "cae_hip.h"
 #include "cae_internal.hpp"
 #include "cae_kernels.hpp"
+#include "cae_kernels_f16.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -113,6 +114,68 @@ static std::vector<float> pack_last(const float *w, int cin, int cout, int ks) {
     return out;
 }
 
+// ---- f16x3 packing -------------------------------------------------------------------------------
+static inline void split_half(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+// weights -> [q][ky][kx][ct][hl][lane][8]: W(cout = 32ct + (lane&31), cin = 16q + 8(lane>>5) + j, ky, kx)
+static std::vector<_Float16> pack_weights_f16(const float *w, bool transposed, int cin, int cout, int ks, int ct) {
+    const int nq = (cin + 15) / 16;
+    std::vector<_Float16> out((size_t)nq * ks * ks * ct * 2 * 512, (_Float16)0.0f);
+    for (int q = 0; q < nq; ++q)
+        for (int ky = 0; ky < ks; ++ky)
+            for (int kx = 0; kx < ks; ++kx)
+                for (int t = 0; t < ct; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = 32 * t + (lane & 31);
+                            const int ci = 16 * q + 8 * (lane >> 5) + j;
+                            float v = 0.0f;
+                            if (co < cout && ci < cin)
+                                v = transposed ? w[(((size_t)ci * cout + co) * ks + ky) * ks + kx]
+                                               : w[(((size_t)co * cin + ci) * ks + ky) * ks + kx];
+                            _Float16 hi, lo;
+                            split_half(v, hi, lo);
+                            const size_t base = (((((size_t)q * ks + ky) * ks + kx) * ct + t) * 2) * 512;
+                            out[base + (size_t)lane * 8 + j] = hi;
+                            out[base + 512 + (size_t)lane * 8 + j] = lo;
+                        }
+    return out;
+}
+
+// gamma -> [jt][co][s][hl][lane][8]: G(c = 32co + (lane&31), j = 32jt + row(8s+e) + 4(lane>>5))
+static std::vector<_Float16> pack_gamma_f16(const float *g, int C, int ct) {
+    std::vector<_Float16> out((size_t)ct * ct * 2 * 2 * 512, (_Float16)0.0f);
+    for (int jt = 0; jt < ct; ++jt)
+        for (int co = 0; co < ct; ++co)
+            for (int s2 = 0; s2 < 2; ++s2)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = 8 * s2 + e;
+                        const int c = 32 * co + (lane & 31);
+                        const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const float v = (c < C && j < C) ? g[(size_t)c * C + j] : 0.0f;
+                        _Float16 hi, lo;
+                        split_half(v, hi, lo);
+                        const size_t base = ((((size_t)jt * ct + co) * 2 + s2) * 2) * 512;
+                        out[base + (size_t)lane * 8 + e] = hi;
+                        out[base + 512 + (size_t)lane * 8 + e] = lo;
+                    }
+    return out;
+}
+
+static int upload_raw(const void *src, size_t bytes, void **dev) {
+    if (*dev) {
+        (void)hipFree(*dev);
+        *dev = nullptr;
+    }
+    HIP_TRY(hipMalloc(dev, bytes));
+    HIP_TRY(hipMemcpy(*dev, src, bytes, hipMemcpyHostToDevice));
+    return CAE_OK;
+}
+
 static int upload(const std::vector<float> &v, float **dev) {
     if (*dev) {
         (void)hipFree(*dev);
@@ -158,9 +221,13 @@ Model::~Model() {
             if (l.gp) (void)hipFree(l.gp);
             if (l.beta) (void)hipFree(l.beta);
             if (l.wp_edge) (void)hipFree(l.wp_edge);
+            if (l.wp16) (void)hipFree(l.wp16);
+            if (l.gp16) (void)hipFree(l.gp16);
         }
     for (int i = 0; i < 3; ++i)
         if (ws[i]) (void)hipFree(ws[i]);
+    for (int i = 0; i < 2; ++i)
+        if (ws16[i]) (void)hipFree(ws16[i]);
     if (zero) (void)hipFree(zero);
     if (medians_dev) (void)hipFree(medians_dev);
 }
@@ -247,6 +314,34 @@ static int launch_last_t(const LayerArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
     HIP_TRY(hipGetLastError());
     return CAE_OK;
+}
+
+template <int KS, int CT, bool GDN>
+static int launch_conv_f16_t(const LayerArgs &a, hipStream_t st) {
+    constexpr int NW = 4;
+    constexpr int WH = 2 * 16 + KS - 2;
+    constexpr int HALO_INSTR = (4 * 16 * WH + 63) / 64;
+    constexpr int CONV_STAGE = KS * CT * 2 * 1024 + HALO_INSTR * 1024;
+    constexpr int G_BYTES = GDN ? CT * 4096 : 0;
+    constexpr int LDS = 2 * (CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES);
+    static_assert(LDS <= 160 * 1024, "stage does not fit the LDS");
+    auto kern = conv_s2_f16_kernel<KS, CT, GDN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int launch_conv_f16(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
+    if (ks != 3) return fail(CAE_ERR_UNSUPPORTED, "f16x3 path: kernel_size 3 only");
+    if (ct == 4) return gdn ? launch_conv_f16_t<3, 4, true>(a, st) : launch_conv_f16_t<3, 4, false>(a, st);
+    if (ct == 6) return gdn ? fail(CAE_ERR_UNSUPPORTED, "f16x3 GDN with 192 channels") : launch_conv_f16_t<3, 6, false>(a, st);
+    return fail(CAE_ERR_UNSUPPORTED, "f16x3 path: unsupported channel tiles %d", ct);
 }
 
 template <int CT, bool INV>
@@ -429,6 +524,14 @@ int cae_model_set_layer(cae_model_t *mm, int track, int index, int cin, int cout
     } else if (track == CAE_SYNTHESIS && index == m->L - 1 && cout <= 4 && beta == nullptr) {
         if ((rc = upload(pack_last(w, cin, cout, m->ks), &l.wp_edge))) return rc;
     }
+    if (m->precision == 1) {
+        auto w16 = pack_weights_f16(w, track == CAE_SYNTHESIS, cin, cout, m->ks, ct);
+        if ((rc = upload_raw(w16.data(), w16.size() * sizeof(_Float16), &l.wp16))) return rc;
+        if (gamma) {
+            auto g16 = pack_gamma_f16(gamma, cout, ct);
+            if ((rc = upload_raw(g16.data(), g16.size() * sizeof(_Float16), &l.gp16))) return rc;
+        }
+    }
     l.gdn = beta != nullptr;
     if (l.gdn) {
         std::vector<float> b(ct * 32, 1.0f);
@@ -436,6 +539,15 @@ int cae_model_set_layer(cae_model_t *mm, int track, int index, int cin, int cout
         if ((rc = upload(b, &l.beta))) return rc;
         if ((rc = upload(pack_gamma(gamma, cout, ct), &l.gp))) return rc;
     }
+    return CAE_OK;
+}
+
+int cae_model_set_precision(cae_model_t *mm, int precision) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m) return fail(CAE_ERR_ARG, "NULL model");
+    if (precision != 0 && precision != 1) return fail(CAE_ERR_ARG, "precision must be 0 (fp32) or 1 (f16x3)");
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->precision = precision;
     return CAE_OK;
 }
 
@@ -532,6 +644,41 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
             FirstArgs f{tiles, fmt == CAE_FMT_U8_HWC ? 1 : 0, l.cin};
             a.wp = l.wp_edge;
             if ((rc = launch_first(m->ks, l.ct, l.gdn, a, f, st))) return rc;
+        } else if (m->precision == 1 && l.wp16 && (l.ct == 4 || (l.ct == 6 && !l.gdn)) && m->ks == 3 &&
+                   (cur_planes % 2) == 0) {
+            // f16x3 kernel; bring-up form: fp32 C8 <-> split C8S conversions on both sides
+            const size_t in_pix = (size_t)n * cur_planes * ch * cw;
+            const size_t out_pix = (size_t)n * l.ct * 4 * a.OH * a.OW;
+            for (int b = 0; b < 2; ++b) {
+                const size_t need = (b == 0 ? in_pix : out_pix) * 32;
+                if (m->ws16_bytes[b] < need) {
+                    if (m->ws16[b]) {
+                        HIP_TRY(hipDeviceSynchronize());
+                        (void)hipFree(m->ws16[b]);
+                    }
+                    HIP_TRY(hipMalloc(&m->ws16[b], need));
+                    m->ws16_bytes[b] = need;
+                }
+            }
+            hipLaunchKernelGGL(c8_to_c8s_kernel, dim3(ew_grid(in_pix)), dim3(256), 0, st, cur, (char *)m->ws16[0],
+                               in_pix);
+            LayerArgs b16 = a;
+            b16.in = (const float *)m->ws16[0];
+            b16.wp = (const float *)l.wp16;
+            b16.gp = (const float *)l.gp16;
+            b16.cci = (l.cin + 15) / 16;
+            b16.tiles_y = (a.OH + 15) / 16;
+            if (!last) b16.out = m->ws16[1];
+            prof.end();  // (conversion kernel is not part of the layer's time)
+            prof.ev.pop_back();
+            prof.begin();
+            if ((rc = launch_conv_f16(m->ks, l.ct, l.gdn, b16, st))) return rc;
+            prof.end();
+            if (!last)
+                hipLaunchKernelGGL(c8s_to_c8_kernel, dim3(ew_grid(out_pix)), dim3(256), 0, st,
+                                   (const char *)m->ws16[1], (float *)a.out, out_pix);
+            HIP_TRY(hipGetLastError());
+            prof.begin();
         } else {
             if ((rc = launch_conv(m->ks, l.ct, l.gdn, a, st))) return rc;
         }

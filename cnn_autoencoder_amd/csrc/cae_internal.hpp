@@ -20,6 +20,8 @@ struct Layer {
     float *gp = nullptr;    // packed gamma (device)
     float *beta = nullptr;  // [ct*32] (device)
     float *wp_edge = nullptr;  // packed weights of the specialised first-conv / last-deconv kernel, or null
+    void *wp16 = nullptr;      // f16x3 path: packed hi/lo weights
+    void *gp16 = nullptr;      // f16x3 path: packed hi/lo gamma
 };
 
 // Integer tables of the factorized entropy model + per-row encoder constants.
@@ -52,6 +54,9 @@ struct Model {
     size_t ws_bytes[3] = {0, 0, 0};
     std::mutex mu;
     // profiling: per track, per profiled call, the event pairs of every launched kernel
+    int precision = 0;  // 0 = fp32 MFMA, 1 = f16x3 split MFMA
+    void *ws16[2] = {nullptr, nullptr};
+    size_t ws16_bytes[2] = {0, 0};
     bool profiling = false;
     std::vector<std::vector<std::pair<void *, void *>>> prof[2];
     int ensure_ws(int which, size_t bytes);

@@ -157,6 +157,14 @@ class _Track(nn.Module):
                 if isinstance(mod, GDN):
                     mod._owner = (ref, i)
 
+    def precision_code(self) -> int:
+        """0 = exact fp32 MFMA, 1 = f16x3 split MFMA (attribute `precision`, default from CAE_PRECISION)."""
+        import os
+        prec = getattr(self, 'precision', None) or os.environ.get('CAE_PRECISION', 'fp32')
+        if prec not in ('fp32', 'f16x3'):
+            raise ValueError(f"precision must be 'fp32' or 'f16x3', got {prec!r}")
+        return 1 if prec == 'f16x3' else 0
+
     def _units(self):
         return list(getattr(self, self._track_attr))
 
@@ -167,6 +175,7 @@ class _Track(nn.Module):
         _lib.require_gpu()
         if self._handle is None:
             self._handle = _lib.Handle(*self._dims)
+            _lib.check(_lib.lib().cae_model_set_precision(self._handle.ptr, self.precision_code()))
         ver = self._param_versions()
         if ver != self._versions:
             L = _lib.lib()

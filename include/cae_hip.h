@@ -66,6 +66,12 @@ int cae_model_set_layer(cae_model_t *m, int track, int index, int cin, int cout,
                         const float *weight_host, const float *bias_host,
                         const float *beta_eff_host, const float *gamma_eff_host);
 
+/* Arithmetic of the conv / GDN contraction: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32),
+ * 1 = "f16x3": every operand split into two f16 halves, three f16 MFMAs per product, fp32
+ * accumulate (22 significant bits; same 1e-4 parity bar, ~5x less matrix-pipe time).  Set before
+ * cae_model_set_layer.  (No reference counterpart: the reference computes in fp32 on ATen.) */
+int cae_model_set_precision(cae_model_t *m, int precision);
+
 /* Integer tables of the factorized entropy model, as EntropyBottleneck.update() leaves them
  * (_autoencoders.py:502): quantized_cdf (channels, cdf_stride) int32, cdf_length (channels),
  * offset (channels), medians (channels) float. */
