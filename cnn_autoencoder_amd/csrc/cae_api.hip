@@ -166,6 +166,51 @@ static std::vector<_Float16> pack_gamma_f16(const float *g, int C, int ct) {
     return out;
 }
 
+// first layer f16x3: [s][ct][hl][lane][8]: W(cout = 32ct + (lane&31), tap = 4s + 2(lane>>5) + (j>>2), ch = j&3)
+static std::vector<_Float16> pack_first_f16(const float *w, int cin, int cout, int ks, int ct) {
+    const int ns = (ks * ks + 3) / 4;
+    std::vector<_Float16> out((size_t)ns * ct * 2 * 512, (_Float16)0.0f);
+    for (int s2 = 0; s2 < ns; ++s2)
+        for (int t = 0; t < ct; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = 32 * t + (lane & 31), tap = 4 * s2 + 2 * (lane >> 5) + (j >> 2), ch = j & 3;
+                    float v = 0.0f;
+                    if (co < cout && ch < cin && tap < ks * ks) v = w[((size_t)co * cin + ch) * ks * ks + tap];
+                    _Float16 hi, lo;
+                    split_half(v, hi, lo);
+                    const size_t base = (((size_t)s2 * ct + t) * 2) * 512;
+                    out[base + (size_t)lane * 8 + j] = hi;
+                    out[base + 512 + (size_t)lane * 8 + j] = lo;
+                }
+    return out;
+}
+
+// last layer f16x3: [nd][ndx][q][hl][lane][8]: A(row = lane&15 = 4c + 2py + px, cin = 32q + 8(lane>>4) + j)
+static std::vector<_Float16> pack_last_f16(const float *w, int cin, int cout, int ks) {
+    const int P = ks / 2, dlo = -((P + 1) / 2), dhi = (ks - 1 - P) / 2, nb = dhi - dlo + 1;
+    const int nq = (cin + 31) / 32;
+    std::vector<_Float16> out((size_t)nb * nb * nq * 2 * 512, (_Float16)0.0f);
+    for (int nd = 0; nd < nb; ++nd)
+        for (int ndx = 0; ndx < nb; ++ndx)
+            for (int q = 0; q < nq; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = lane & 15, c = row >> 2, py = (row >> 1) & 1, px = row & 1;
+                        const int ci = 32 * q + 8 * (lane >> 4) + j;
+                        const int ky = 2 * (dlo + nd) + py + P, kx = 2 * (dlo + ndx) + px + P;
+                        float v = 0.0f;
+                        if (c < cout && ci < cin && ky >= 0 && ky < ks && kx >= 0 && kx < ks)
+                            v = w[(((size_t)ci * cout + c) * ks + ky) * ks + kx];
+                        _Float16 hi, lo;
+                        split_half(v, hi, lo);
+                        const size_t base = ((((size_t)nd * nb + ndx) * nq + q) * 2) * 512;
+                        out[base + (size_t)lane * 8 + j] = hi;
+                        out[base + 512 + (size_t)lane * 8 + j] = lo;
+                    }
+    return out;
+}
+
 static int upload_raw(const void *src, size_t bytes, void **dev) {
     if (*dev) {
         (void)hipFree(*dev);
@@ -223,6 +268,7 @@ Model::~Model() {
             if (l.wp_edge) (void)hipFree(l.wp_edge);
             if (l.wp16) (void)hipFree(l.wp16);
             if (l.gp16) (void)hipFree(l.gp16);
+            if (l.wp_edge16) (void)hipFree(l.wp_edge16);
         }
     for (int i = 0; i < 3; ++i)
         if (ws[i]) (void)hipFree(ws[i]);
@@ -324,24 +370,120 @@ static int launch_conv_f16_t(const LayerArgs &a, hipStream_t st) {
     constexpr int CONV_STAGE = KS * CT * 2 * 1024 + HALO_INSTR * 1024;
     constexpr int G_BYTES = GDN ? CT * 4096 : 0;
     constexpr int LDS = 2 * (CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES);
-    static_assert(LDS <= 160 * 1024, "stage does not fit the LDS");
-    auto kern = conv_s2_f16_kernel<KS, CT, GDN>;
+    if constexpr (LDS > 160 * 1024) {
+        return fail(CAE_ERR_UNSUPPORTED, "f16x3: this kernel_size/channel combination exceeds the LDS; use fp32");
+    } else {
+        auto kern = conv_s2_f16_kernel<KS, CT, GDN>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            attr_done = true;
+        }
+        const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
+        HIP_TRY(hipGetLastError());
+        return CAE_OK;
+    }
+}
+
+#define DISPATCH_F16(FN, KS_)                                                               \
+    switch (ct) {                                                                          \
+        case 1: return gdn ? FN<KS_, 1, true>(a, st) : FN<KS_, 1, false>(a, st);           \
+        case 2: return gdn ? FN<KS_, 2, true>(a, st) : FN<KS_, 2, false>(a, st);           \
+        case 4: return gdn ? FN<KS_, 4, true>(a, st) : FN<KS_, 4, false>(a, st);           \
+        case 6:                                                                            \
+            if (!gdn) return FN<KS_, 6, false>(a, st);                                     \
+            return fail(CAE_ERR_UNSUPPORTED, "f16x3: GDN with more than 128 channels is not built; use fp32"); \
+        default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct);      \
+    }
+
+int launch_conv_f16(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
+    if (ks == 3) { DISPATCH_F16(launch_conv_f16_t, 3) }
+    if (ks == 5) { DISPATCH_F16(launch_conv_f16_t, 5) }
+    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+}
+
+template <int KS, int CT, bool GDN>
+static int launch_deconv_f16_t(const LayerArgs &a, hipStream_t st) {
+    constexpr int NW = 8;
+    using G = DeconvGeomF16<KS, CT, NW, GDN>;
+    constexpr int LDS = 2 * G::STAGE_BYTES;
+    if constexpr (LDS > 160 * 1024) {
+        return fail(CAE_ERR_UNSUPPORTED, "f16x3: this kernel_size/channel combination exceeds the LDS; use fp32");
+    } else {
+        auto kern = deconv_s2_f16_kernel<KS, CT, NW, GDN>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            attr_done = true;
+        }
+        const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
+        HIP_TRY(hipGetLastError());
+        return CAE_OK;
+    }
+}
+
+int launch_deconv_f16(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
+    if (ks == 3) { DISPATCH_F16(launch_deconv_f16_t, 3) }
+    if (ks == 5) { DISPATCH_F16(launch_deconv_f16_t, 5) }
+    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+}
+
+template <int KS, int CT, bool GDN>
+static int launch_first_f16_t(const LayerArgs &a, const FirstArgs &f, hipStream_t st) {
+    constexpr int NW = 4;
+    constexpr int WH = 2 * 16 + KS - 2, HH = 4 * NW + KS - 2;
+    constexpr int NS = (KS * KS + 3) / 4;
+    constexpr int LDS = 2 * (GDN ? CT * 4096 : 0) + NS * CT * 2048 + ((HH * WH * 16 + 1023) / 1024) * 1024 + 1024;
+    auto kern = conv_first_f16_kernel<KS, CT, GDN>;
     static bool attr_done = false;
     if (!attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_done = true;
     }
     const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a, f);
     HIP_TRY(hipGetLastError());
     return CAE_OK;
 }
 
-int launch_conv_f16(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
-    if (ks != 3) return fail(CAE_ERR_UNSUPPORTED, "f16x3 path: kernel_size 3 only");
-    if (ct == 4) return gdn ? launch_conv_f16_t<3, 4, true>(a, st) : launch_conv_f16_t<3, 4, false>(a, st);
-    if (ct == 6) return gdn ? fail(CAE_ERR_UNSUPPORTED, "f16x3 GDN with 192 channels") : launch_conv_f16_t<3, 6, false>(a, st);
-    return fail(CAE_ERR_UNSUPPORTED, "f16x3 path: unsupported channel tiles %d", ct);
+int launch_first_f16(int ks, int ct, bool gdn, const LayerArgs &a, const FirstArgs &f, hipStream_t st) {
+#define FIRST_F16(KS_)                                                                                       \
+    switch (ct) {                                                                                            \
+        case 1: return gdn ? launch_first_f16_t<KS_, 1, true>(a, f, st) : launch_first_f16_t<KS_, 1, false>(a, f, st); \
+        case 2: return gdn ? launch_first_f16_t<KS_, 2, true>(a, f, st) : launch_first_f16_t<KS_, 2, false>(a, f, st); \
+        case 4: return gdn ? launch_first_f16_t<KS_, 4, true>(a, f, st) : launch_first_f16_t<KS_, 4, false>(a, f, st); \
+        case 6:                                                                                              \
+            if (!gdn) return launch_first_f16_t<KS_, 6, false>(a, f, st);                                    \
+            return fail(CAE_ERR_UNSUPPORTED, "f16x3: GDN with more than 128 channels is not built; use fp32"); \
+        default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct);                       \
+    }
+    if (ks == 3) { FIRST_F16(3) }
+    if (ks == 5) { FIRST_F16(5) }
+    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+}
+
+template <int KS>
+static int launch_last_f16_t(const LayerArgs &a, hipStream_t st) {
+    constexpr int NW = 4;
+    constexpr int P = KS / 2;
+    constexpr int NB = (KS - 1 - P) / 2 + (P + 1) / 2 + 1;
+    constexpr int HALO_INSTR = (8 * (NW + NB - 1) * (32 + NB - 1) + 63) / 64;
+    const int lds = 2 * HALO_INSTR * 1024 + NB * NB * a.cci * 2048;
+    if (lds > 160 * 1024) return fail(CAE_ERR_UNSUPPORTED, "last-layer weights do not fit the LDS");
+    auto kern = deconv_last_f16_kernel<KS, NW>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int launch_last_f16(int ks, const LayerArgs &a, hipStream_t st) {
+    if (ks == 3) return launch_last_f16_t<3>(a, st);
+    if (ks == 5) return launch_last_f16_t<5>(a, st);
+    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
 }
 
 template <int CT, bool INV>
@@ -525,6 +667,17 @@ int cae_model_set_layer(cae_model_t *mm, int track, int index, int cin, int cout
         if ((rc = upload(pack_last(w, cin, cout, m->ks), &l.wp_edge))) return rc;
     }
     if (m->precision == 1) {
+        if (l.wp_edge16) {
+            (void)hipFree(l.wp_edge16);
+            l.wp_edge16 = nullptr;
+        }
+        if (track == CAE_ANALYSIS && index == 0 && cin <= 4) {
+            auto e16 = pack_first_f16(w, cin, cout, m->ks, ct);
+            if ((rc = upload_raw(e16.data(), e16.size() * sizeof(_Float16), &l.wp_edge16))) return rc;
+        } else if (track == CAE_SYNTHESIS && index == m->L - 1 && cout <= 4 && beta == nullptr) {
+            auto e16 = pack_last_f16(w, cin, cout, m->ks);
+            if ((rc = upload_raw(e16.data(), e16.size() * sizeof(_Float16), &l.wp_edge16))) return rc;
+        }
         auto w16 = pack_weights_f16(w, track == CAE_SYNTHESIS, cin, cout, m->ks, ct);
         if ((rc = upload_raw(w16.data(), w16.size() * sizeof(_Float16), &l.wp16))) return rc;
         if (gamma) {
@@ -583,10 +736,13 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
     std::lock_guard<std::mutex> lk(m->mu);
     int rc;
     if ((rc = m->ensure_device())) return rc;
+    const bool f16 = m->precision == 1;
+    const bool first_fused = f16 ? m->enc[0].wp_edge16 != nullptr : m->enc[0].wp_edge != nullptr;
 
-    // workspace: ws[0] = converted input, ws[1]/ws[2] ping-pong
-    const int p0 = (m->c_org + 7) / 8;
-    size_t in_bytes = m->enc[0].wp_edge ? 0 : (size_t)n * p0 * h * w * 32;  // fused first layer reads the tiles
+    // workspace: ws[0] = converted input, ws[1]/ws[2] ping-pong.  fp32 C8 and split C8S records are
+    // both 32 B per (plane, pixel), so the same buffers serve either precision.
+    const int p0 = f16 ? 2 * ((m->c_org + 15) / 16) : (m->c_org + 7) / 8;
+    size_t in_bytes = first_fused ? 0 : (size_t)n * p0 * h * w * 32;
     size_t maxact = 0;
     {
         int ch = h, cw = w;
@@ -600,16 +756,27 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
     if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
 
     ProfScope prof(m, CAE_ANALYSIS, st);
-    const bool first_fused = m->enc[0].wp_edge != nullptr;
     prof.begin();
     if (!first_fused) {
         const size_t tot = (size_t)n * p0 * h * w;
-        if (fmt == CAE_FMT_U8_HWC)
+        if (f16) {
+            if (fmt == CAE_FMT_U8_HWC) {
+                // rare (more than 4 input channels): uint8 -> fp32 C8 (exact /255) -> split, in place
+                hipLaunchKernelGGL(u8hwc_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint8_t *)tiles,
+                                   (float *)m->ws[0], n, h, w, m->c_org, p0);
+                hipLaunchKernelGGL(c8_to_c8s_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)m->ws[0],
+                                   (char *)m->ws[0], tot);
+            } else {
+                hipLaunchKernelGGL(nchw_to_c8s_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)tiles,
+                                   (char *)m->ws[0], n, m->c_org, h * w, p0);
+            }
+        } else if (fmt == CAE_FMT_U8_HWC) {
             hipLaunchKernelGGL(u8hwc_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint8_t *)tiles,
                                (float *)m->ws[0], n, h, w, m->c_org, p0);
-        else
+        } else {
             hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)tiles,
                                (float *)m->ws[0], n, m->c_org, h * w, p0);
+        }
         HIP_TRY(hipGetLastError());
     }
     prof.end();
@@ -642,43 +809,21 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
         prof.begin();
         if (i == 0 && first_fused) {
             FirstArgs f{tiles, fmt == CAE_FMT_U8_HWC ? 1 : 0, l.cin};
-            a.wp = l.wp_edge;
-            if ((rc = launch_first(m->ks, l.ct, l.gdn, a, f, st))) return rc;
-        } else if (m->precision == 1 && l.wp16 && (l.ct == 4 || (l.ct == 6 && !l.gdn)) && m->ks == 3 &&
-                   (cur_planes % 2) == 0) {
-            // f16x3 kernel; bring-up form: fp32 C8 <-> split C8S conversions on both sides
-            const size_t in_pix = (size_t)n * cur_planes * ch * cw;
-            const size_t out_pix = (size_t)n * l.ct * 4 * a.OH * a.OW;
-            for (int b = 0; b < 2; ++b) {
-                const size_t need = (b == 0 ? in_pix : out_pix) * 32;
-                if (m->ws16_bytes[b] < need) {
-                    if (m->ws16[b]) {
-                        HIP_TRY(hipDeviceSynchronize());
-                        (void)hipFree(m->ws16[b]);
-                    }
-                    HIP_TRY(hipMalloc(&m->ws16[b], need));
-                    m->ws16_bytes[b] = need;
-                }
+            a.tiles_y = (a.OH + 7) / 8;
+            if (f16) {
+                a.wp = (const float *)l.wp_edge16;
+                a.gp = (const float *)l.gp16;
+                if ((rc = launch_first_f16(m->ks, l.ct, l.gdn, a, f, st))) return rc;
+            } else {
+                a.wp = l.wp_edge;
+                if ((rc = launch_first(m->ks, l.ct, l.gdn, a, f, st))) return rc;
             }
-            hipLaunchKernelGGL(c8_to_c8s_kernel, dim3(ew_grid(in_pix)), dim3(256), 0, st, cur, (char *)m->ws16[0],
-                               in_pix);
-            LayerArgs b16 = a;
-            b16.in = (const float *)m->ws16[0];
-            b16.wp = (const float *)l.wp16;
-            b16.gp = (const float *)l.gp16;
-            b16.cci = (l.cin + 15) / 16;
-            b16.tiles_y = (a.OH + 15) / 16;
-            if (!last) b16.out = m->ws16[1];
-            prof.end();  // (conversion kernel is not part of the layer's time)
-            prof.ev.pop_back();
-            prof.begin();
-            if ((rc = launch_conv_f16(m->ks, l.ct, l.gdn, b16, st))) return rc;
-            prof.end();
-            if (!last)
-                hipLaunchKernelGGL(c8s_to_c8_kernel, dim3(ew_grid(out_pix)), dim3(256), 0, st,
-                                   (const char *)m->ws16[1], (float *)a.out, out_pix);
-            HIP_TRY(hipGetLastError());
-            prof.begin();
+        } else if (f16) {
+            a.wp = (const float *)l.wp16;
+            a.gp = (const float *)l.gp16;
+            a.cci = (l.cin + 15) / 16;
+            a.tiles_y = (a.OH + 15) / 16;
+            if ((rc = launch_conv_f16(m->ks, l.ct, l.gdn, a, st))) return rc;
         } else {
             if ((rc = launch_conv(m->ks, l.ct, l.gdn, a, st))) return rc;
         }
@@ -703,8 +848,10 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
     std::lock_guard<std::mutex> lk(m->mu);
     int rc;
     if ((rc = m->ensure_device())) return rc;
+    const bool f16 = m->precision == 1;
 
-    const int p0 = (m->c_bn + 7) / 8;
+    // planes of the converted latents: padded so whole MFMA k-steps can be read (zero channels)
+    const int p0 = f16 ? 4 * ((m->c_bn + 31) / 32) : (m->c_bn + 7) / 8;
     size_t in_bytes = (size_t)n * p0 * lh * lw * 32;
     size_t maxact = 0;
     {
@@ -721,8 +868,12 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
     ProfScope prof(m, CAE_SYNTHESIS, st);
     prof.begin();
     const size_t tot = (size_t)n * p0 * lh * lw;
-    hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (float *)m->ws[0], n, m->c_bn,
-                       lh * lw, p0);
+    if (f16)
+        hipLaunchKernelGGL(nchw_to_c8s_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (char *)m->ws[0], n,
+                           m->c_bn, lh * lw, p0);
+    else
+        hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (float *)m->ws[0], n,
+                           m->c_bn, lh * lw, p0);
     HIP_TRY(hipGetLastError());
     prof.end();
 
@@ -752,10 +903,25 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
         a.tiles_y = (ch + CAE_DECONV_NW - 1) / CAE_DECONV_NW;
         a.outfmt = last ? (fmt == CAE_FMT_U8_HWC ? OUT_U8HWC : OUT_NCHW) : OUT_C8;
         prof.begin();
-        if (last && l.wp_edge) {
+        if (f16) {
+            a.gp = (const float *)l.gp16;
+            if (last && l.wp_edge16) {
+                a.wp = (const float *)l.wp_edge16;
+                a.cci = (l.cin + 31) / 32;
+                a.tiles_x = (cw + 31) / 32;
+                a.tiles_y = (ch + 3) / 4;
+                if ((rc = launch_last_f16(m->ks, a, st))) return rc;
+            } else {
+                a.wp = (const float *)l.wp16;
+                a.cci = (l.cin + 15) / 16;
+                a.tiles_y = (ch + 7) / 8;
+                if ((rc = launch_deconv_f16(m->ks, l.ct, l.gdn, a, st))) return rc;
+            }
+        } else if (last && l.wp_edge) {
             a.wp = l.wp_edge;
             a.cci = (l.cin + 15) / 16;
             a.tiles_x = (cw + 63) / 64;
+            a.tiles_y = (ch + 3) / 4;
             if ((rc = launch_last(m->ks, a, st))) return rc;
         } else {
             if ((rc = launch_deconv(m->ks, l.ct, l.gdn, a, st))) return rc;
@@ -763,8 +929,12 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
         prof.end();
         if (!last && bridges && bridges[i]) {
             const size_t t2 = (size_t)n * l.cout * a.OH * a.OW;
-            hipLaunchKernelGGL(c8_to_nchw_kernel, dim3(ew_grid(t2)), dim3(256), 0, st, (const float *)a.out, bridges[i],
-                               n, l.cout, a.OH * a.OW, l.ct * 4);
+            if (f16)
+                hipLaunchKernelGGL(c8s_to_nchw_kernel, dim3(ew_grid(t2)), dim3(256), 0, st, (const char *)a.out,
+                                   bridges[i], n, l.cout, a.OH * a.OW, l.ct * 4);
+            else
+                hipLaunchKernelGGL(c8_to_nchw_kernel, dim3(ew_grid(t2)), dim3(256), 0, st, (const float *)a.out,
+                                   bridges[i], n, l.cout, a.OH * a.OW, l.ct * 4);
             HIP_TRY(hipGetLastError());
         }
         cur = (const float *)a.out;

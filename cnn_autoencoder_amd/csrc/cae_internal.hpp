@@ -22,6 +22,7 @@ struct Layer {
     float *wp_edge = nullptr;  // packed weights of the specialised first-conv / last-deconv kernel, or null
     void *wp16 = nullptr;      // f16x3 path: packed hi/lo weights
     void *gp16 = nullptr;      // f16x3 path: packed hi/lo gamma
+    void *wp_edge16 = nullptr; // f16x3 path: packed weights of the first-conv / last-deconv kernel
 };
 
 // Integer tables of the factorized entropy model + per-row encoder constants.

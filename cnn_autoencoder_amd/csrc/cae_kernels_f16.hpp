@@ -255,6 +255,409 @@ __global__ void __launch_bounds__(256, 1) conv_s2_f16_kernel(const LayerArgs p) 
     }
 }
 
+// =================================================================================================
+// conv_first_f16_kernel: first analysis layer (Cin <= 4) on f16x3, input uint8 HWC or float NCHW.
+//   K = (tap, 4 channels): k-step s, lane half h covers taps 4s+2h, 4s+2h+1 (two float4 halo reads).
+//   packed weights: [s][ct][hl][lane][8]: W(cout, tap = 4s + 2(lane>>5) + (j>>2), ch = j&3)
+//   Output write (fp32-sized C8S records) bounds this layer: it is HBM-write limited.
+// =================================================================================================
+template <int KS, int CT, bool GDN>
+__global__ void __launch_bounds__(256, 2) conv_first_f16_kernel(const LayerArgs p, const FirstArgs f) {
+    constexpr int NW = 4;
+    constexpr int PAD = KS / 2;
+    constexpr int TX = 16, TY = 2 * NW;
+    constexpr int WH = 2 * TX + KS - 2, HH = 2 * TY + KS - 2;
+    constexpr int NS = (KS * KS + 3) / 4;  // k-steps of 4 taps
+    constexpr int W_BYTES = NS * CT * 2048;
+    constexpr int G_BYTES = GDN ? CT * 4096 : 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *gbuf = smem;
+    char *wbuf = smem + 2 * G_BYTES;
+    char *hbuf = wbuf + W_BYTES;
+    float *lut = (float *)(hbuf + ((HH * WH * 16 + 1023) / 1024) * 1024);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n = bid / p.tiles_y;
+    const int oy0 = ty * TY, ox0 = tx * TX;
+
+    int sc = 0;
+    if (GDN) issue_gamma0<CT, NW>(p, gbuf, wave, lane);
+    for (int i = threadIdx.x; i < W_BYTES / 16; i += NW * 64)
+        *(f32x4 *)(wbuf + i * 16) = *(const f32x4 *)((const char *)p.wp + i * 16);
+    if (f.in_is_u8) {
+        for (int i = threadIdx.x; i < 256; i += NW * 64) lut[i] = (float)i / 255.0f;
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < HH * WH; i += NW * 64) {
+        const int r = i / WH, x = i - r * WH;
+        const int iy = reflect_idx(2 * oy0 - PAD + r, p.H), ix = reflect_idx(2 * ox0 - PAD + x, p.W);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (f.in_is_u8) {
+            const uint8_t *src = (const uint8_t *)f.in + (((size_t)n * p.H + iy) * p.W + ix) * f.cin;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < f.cin) v[c] = lut[src[c]];
+        } else {
+            const float *src = (const float *)f.in + (size_t)n * f.cin * p.H * p.W + (size_t)iy * p.W + ix;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < f.cin) v[c] = src[(size_t)c * p.H * p.W];
+        }
+        *(f32x4 *)(hbuf + i * 16) = v;
+    }
+    __syncthreads();
+
+    f32x16 acc[1][CT];
+    init_acc<CT>(acc[0], p.bias, h, 0.0f);
+    const int wrow = 2 * wave + (m >> 4);
+    const char *hb = hbuf + ((2 * wrow) * WH + 2 * (m & 15)) * 16;
+    const char *wb = wbuf + lane * 16;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        f16x8 bh, bl;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // tap index of this lane half: 4s + 2h + half  (compile-time per h)
+            const int t0 = 4 * s + half, t1 = 4 * s + 2 + half;
+            const int o0 = t0 < KS * KS ? ((t0 / KS) * WH + (t0 % KS)) * 16 : -1;
+            const int o1 = t1 < KS * KS ? ((t1 / KS) * WH + (t1 % KS)) * 16 : -1;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (o0 >= 0) v0 = *(const f32x4 *)(hb + o0);
+            if (o1 >= 0) v1 = *(const f32x4 *)(hb + o1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float v = h ? v1[c] : v0[c];
+                _Float16 a, b;
+                split_f16(v, a, b);
+                bh[4 * half + c] = a;
+                bl[4 * half + c] = b;
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const f16x8 ah = *(const f16x8 *)(wb + ((s * CT + ct) * 2 + 0) * 1024);
+            const f16x8 al = *(const f16x8 *)(wb + ((s * CT + ct) * 2 + 1) * 1024);
+            acc[0][ct] = mfma3(ah, al, bh, bl, acc[0][ct]);
+        }
+    }
+    if constexpr (GDN) {
+        gdn_stages_f16<CT, 1, NW, false, G_BYTES>(acc, p, gbuf, sc, wave, lane, [](char *) {});
+    }
+    const int oy = oy0 + wrow, ox = ox0 + (m & 15);
+    store_tiles_f16<CT>(acc[0], p, n, oy, ox, h, oy < p.OH && ox < p.OW);
+}
+
+// =================================================================================================
+// deconv_s2_f16_kernel: stride-2 transposed conv (+bias) (+IGDN), f16x3, C8S in.
+//   block = NW waves, wave w owns INPUT row ty0+w, 32 input columns; per output-row parity py two
+//   accumulator sets (px = 0, 1).  stage = (py, 16-channel chunk q, kernel row ky(py, d)):
+//     weights [kx][ct][hl][64][8 f16]  +  halo [pl][hl][NW rows][WH][16 B]
+// =================================================================================================
+template <int KS, int CT, int NW, bool IGDN>
+struct DeconvGeomF16 {
+    static constexpr int P = KS / 2;
+    static constexpr int DLO = -((P + 1) / 2), DHI = (KS - 1 - P) / 2;
+    static constexpr int WH = 32 + DHI - DLO;
+    static constexpr int PLANE_PIECES = NW * WH;
+    static constexpr int HALO_PIECES = 4 * PLANE_PIECES;
+    static constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;
+    static constexpr int W_INSTR = KS * CT * 2;
+    static constexpr int W_BYTES = W_INSTR * 1024;
+    static constexpr int G_BYTES = IGDN ? CT * 4096 : 0;
+    static constexpr int CONV_STAGE = W_BYTES + HALO_INSTR * 1024;
+    static constexpr int STAGE_BYTES = CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES;
+    static constexpr int MAXP = (HALO_INSTR + NW - 1) / NW;
+    static constexpr int dmin(int py) { return -((py + P) / 2); }
+    static constexpr int nky(int py) { return (KS - 1 - py - P) / 2 - dmin(py) + 1; }
+};
+
+template <int KS, int CT, int NW, bool IGDN, int PY>
+__device__ __forceinline__ void deconv_issue_f16(const LayerArgs &p, const char *in_n, size_t plane_bytes, int s,
+                                                 char *buf, const int *hrow, const long *hbase, int wave, int lane) {
+    using G = DeconvGeomF16<KS, CT, NW, IGDN>;
+    constexpr int NKY = G::nky(PY);
+    const int q = s / NKY, d = G::dmin(PY) + (s - q * NKY);
+    const int ky = 2 * d + PY + G::P;
+    const char *wsrc = (const char *)p.wp + (size_t)(q * KS + ky) * G::W_BYTES;
+#pragma unroll
+    for (int i = 0; i < (G::W_INSTR + NW - 1) / NW; ++i) {
+        const int j = wave + i * NW;
+        if (j < G::W_INSTR) glds16(wsrc + j * 1024 + lane * 16, buf + j * 1024);
+    }
+    const char *planes = in_n + (size_t)(2 * q) * plane_bytes;
+#pragma unroll
+    for (int i = 0; i < G::MAXP; ++i) {
+        const int j = wave + i * NW;
+        if (j < G::HALO_INSTR) {
+            const int iy = hrow[i] - d;
+            const bool ok = iy >= 0 && iy < p.H && hbase[i] >= 0;
+            const char *src = ok ? planes + hbase[i] + (size_t)iy * p.W * 32 : (const char *)p.zero;
+            glds16(src, buf + G::W_BYTES + j * 1024);
+        }
+    }
+}
+
+template <int KS, int CT, int NW, bool IGDN, int PY>
+__device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char *in_n, size_t plane_bytes, char *smem,
+                                                 int &sc, const int *hrow, const long *hbase, int wave, int lane,
+                                                 int b_off, int n, int iy, int ix, bool valid) {
+    using G = DeconvGeomF16<KS, CT, NW, IGDN>;
+    constexpr int P = G::P;
+    constexpr int STAGE_BYTES = G::STAGE_BYTES;
+    constexpr int B_HL = G::PLANE_PIECES * 16;
+    const int h = lane >> 5;
+    const int NS = p.cci * G::nky(PY);
+    f32x16 acc[2][1][CT];  // [px][pt = 1][ct]
+    init_acc<CT>(acc[0][0], p.bias, h, 0.0f);
+    init_acc<CT>(acc[1][0], p.bias, h, 0.0f);
+
+    for (int s = 0; s < NS; ++s) {
+        wait_vm0();
+        __syncthreads();
+        char *cur = smem + (sc & 1) * STAGE_BYTES;
+        char *nxt = smem + ((sc + 1) & 1) * STAGE_BYTES;
+        if (s + 1 < NS) {
+            deconv_issue_f16<KS, CT, NW, IGDN, PY>(p, in_n, plane_bytes, s + 1, nxt, hrow, hbase, wave, lane);
+        } else if (IGDN) {
+            issue_gamma0<CT, NW>(p, nxt, wave, lane);
+        } else if (PY == 0) {
+            deconv_issue_f16<KS, CT, NW, IGDN, 1>(p, in_n, plane_bytes, 0, nxt, hrow, hbase, wave, lane);
+        }
+        const char *wb = cur + lane * 16;
+        const char *hb = cur + b_off;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const int px = (kx + P) & 1;
+            const int dx = (kx - P - px) / 2;
+            const f16x8 bh = *(const f16x8 *)(hb - dx * 16);
+            const f16x8 bl = *(const f16x8 *)(hb - dx * 16 + B_HL);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const f16x8 ah = *(const f16x8 *)(wb + ((kx * CT + ct) * 2 + 0) * 1024);
+                const f16x8 al = *(const f16x8 *)(wb + ((kx * CT + ct) * 2 + 1) * 1024);
+                if (px == 0)
+                    acc[0][0][ct] = mfma3(ah, al, bh, bl, acc[0][0][ct]);
+                else
+                    acc[1][0][ct] = mfma3(ah, al, bh, bl, acc[1][0][ct]);
+            }
+        }
+        ++sc;
+    }
+
+    if constexpr (IGDN) {
+        gdn_stages_f16<CT, 1, NW, true, STAGE_BYTES>(acc[0], p, smem, sc, wave, lane,
+                                                     [&](char *nxt) { issue_gamma0<CT, NW>(p, nxt, wave, lane); });
+        store_tiles_f16<CT>(acc[0][0], p, n, 2 * iy + PY, 2 * ix, h, valid);
+        gdn_stages_f16<CT, 1, NW, true, STAGE_BYTES>(acc[1], p, smem, sc, wave, lane, [&](char *nxt) {
+            if (PY == 0)
+                deconv_issue_f16<KS, CT, NW, IGDN, 1>(p, in_n, plane_bytes, 0, nxt, hrow, hbase, wave, lane);
+        });
+        store_tiles_f16<CT>(acc[1][0], p, n, 2 * iy + PY, 2 * ix + 1, h, valid);
+    } else {
+        store_tiles_f16<CT>(acc[0][0], p, n, 2 * iy + PY, 2 * ix, h, valid);
+        store_tiles_f16<CT>(acc[1][0], p, n, 2 * iy + PY, 2 * ix + 1, h, valid);
+    }
+}
+
+template <int KS, int CT, int NW, bool IGDN>
+__global__ void __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) deconv_s2_f16_kernel(const LayerArgs p) {
+    using G = DeconvGeomF16<KS, CT, NW, IGDN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n = bid / p.tiles_y;
+    const int iy0 = ty * NW, ix0 = tx * 32;
+
+    int hrow[G::MAXP];
+    long hbase[G::MAXP];  // byte offset of (plane-in-chunk, half, column) inside the chunk, < 0: outside
+#pragma unroll
+    for (int i = 0; i < G::MAXP; ++i) {
+        int pc = (wave + i * NW) * 64 + lane;
+        pc = pc < G::HALO_PIECES ? pc : G::HALO_PIECES - 1;
+        const int plhl = pc / G::PLANE_PIECES;
+        const int rem = pc - plhl * G::PLANE_PIECES;
+        const int r = rem / G::WH, x = rem - r * G::WH;
+        const int ix = ix0 + x - G::DHI;
+        hrow[i] = iy0 + r;
+        hbase[i] = (ix >= 0 && ix < p.W)
+                       ? (long)(plhl >> 1) * (long)((size_t)p.H * p.W * 32) + (long)ix * 32 + (plhl & 1) * 16
+                       : -1;
+    }
+    const size_t plane_bytes = (size_t)p.H * p.W * 32;
+    const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
+    // B operand: halo [pl = h][hl][row = wave][x = m + DHI - dx]
+    const int b_off = G::W_BYTES + (((2 * h) * NW + wave) * G::WH + m + G::DHI) * 16;
+    const int iy = iy0 + wave, ix = ix0 + m;
+    const bool valid = iy < p.H && ix < p.W;
+    int sc = 0;
+    deconv_issue_f16<KS, CT, NW, IGDN, 0>(p, in_n, plane_bytes, 0, smem, hrow, hbase, wave, lane);
+    deconv_phase_f16<KS, CT, NW, IGDN, 0>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, n, iy, ix,
+                                          valid);
+    deconv_phase_f16<KS, CT, NW, IGDN, 1>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, n, iy, ix,
+                                          valid);
+}
+
+// =================================================================================================
+// deconv_last_f16_kernel: last synthesis layer (Cout <= 4, no IGDN) on v_mfma_f32_16x16x32_f16, C8S in.
+//   D rows = 4c + p (p = 2 py + px), cols = 16 input pixels; K = (neighbour, cin); one MFMA k-step
+//   = 32 channels = 4 planes (lane group g = lane>>4 supplies plane 4q+g).
+//   packed weights: [nd][ndx][q][hl][lane][8]: A(row = lane&15, cin = 32q + 8(lane>>4) + j)
+//   LDS: halo chunk [g][hl][row][x] of 16-byte pieces, double-buffered; all weights resident.
+// =================================================================================================
+template <int KS, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) deconv_last_f16_kernel(const LayerArgs p) {
+    constexpr int P = KS / 2;
+    constexpr int DLO = -((P + 1) / 2), DHI = (KS - 1 - P) / 2;
+    constexpr int NB = DHI - DLO + 1;
+    constexpr int TXC = 32, NT = TXC / 16;
+    constexpr int WH = TXC + NB - 1, HR = NW + NB - 1;
+    constexpr int PLANE_PIECES = HR * WH;
+    constexpr int HALO_PIECES = 8 * PLANE_PIECES;  // [g(4)][hl(2)]
+    constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;
+    constexpr int STAGE_BYTES = HALO_INSTR * 1024;
+    constexpr int MAXP = (HALO_INSTR + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, col = lane & 15;
+    const int nq = p.cci;  // 32-channel groups
+    char *wbuf = smem + 2 * STAGE_BYTES;
+
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n = bid / p.tiles_y;
+    const int iy0 = ty * NW, ix0 = tx * TXC;
+    const size_t plane_bytes = (size_t)p.H * p.W * 32;
+    const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
+
+    long hsrc[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        int pc = (wave + i * NW) * 64 + lane;
+        pc = pc < HALO_PIECES ? pc : HALO_PIECES - 1;
+        const int ghl = pc / PLANE_PIECES;
+        const int rem = pc - ghl * PLANE_PIECES;
+        const int r = rem / WH, x = rem - r * WH;
+        const int sy = iy0 - DHI + r, sx = ix0 - DHI + x;
+        const bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+        hsrc[i] = ok ? (long)(ghl >> 1) * (long)plane_bytes + ((long)sy * p.W + sx) * 32 + (ghl & 1) * 16 : -1;
+    }
+    auto issue = [&](int q, char *buf) {
+        const char *base = in_n + (size_t)(4 * q) * plane_bytes;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int j = wave + i * NW;
+            if (j < HALO_INSTR)
+                glds16(hsrc[i] >= 0 ? (const void *)(base + hsrc[i]) : (const void *)p.zero, buf + j * 1024);
+        }
+    };
+    issue(0, smem);
+    const int w_bytes = NB * NB * nq * 2048;
+    for (int i = threadIdx.x; i < w_bytes / 16; i += NW * 64)
+        *(f32x4 *)(wbuf + i * 16) = *(const f32x4 *)((const char *)p.wp + i * 16);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = (p.bias && g < p.cout) ? p.bias[g] : 0.0f;
+
+    for (int q = 0; q < nq; ++q) {
+        wait_vm0();
+        __syncthreads();
+        char *cur = smem + (q & 1) * STAGE_BYTES;
+        if (q + 1 < nq) issue(q + 1, smem + ((q + 1) & 1) * STAGE_BYTES);
+#pragma unroll
+        for (int nd = 0; nd < NB; ++nd)
+#pragma unroll
+            for (int ndx = 0; ndx < NB; ++ndx) {
+                const int hr = wave - (DLO + nd) + DHI;
+                const int hx = col - (DLO + ndx) + DHI;
+                const char *wq = wbuf + (((nd * NB + ndx) * nq + q) * 2) * 1024 + lane * 16;
+                const f16x8 ah = *(const f16x8 *)(wq);
+                const f16x8 al = *(const f16x8 *)(wq + 1024);
+                const char *hb = cur + (((2 * g) * HR + hr) * WH + hx) * 16;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f16x8 bh = *(const f16x8 *)(hb + t * 256);
+                    const f16x8 bl = *(const f16x8 *)(hb + t * 256 + PLANE_PIECES * 16);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
+                }
+            }
+    }
+    const int iy = iy0 + wave;
+    if (iy < p.H && g < p.cout) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int ix = ix0 + 16 * t + col;
+            if (ix < p.W) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int oy = 2 * iy + (r >> 1), ox = 2 * ix + (r & 1);
+                    if (p.outfmt == OUT_U8HWC) {
+                        float v = acc[t][r] * 255.0f;
+                        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+                        ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + g] = (uint8_t)v;
+                    } else {
+                        ((float *)p.out)[(((size_t)n * p.cout + g) * p.OH + oy) * p.OW + ox] = acc[t][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// fp32 NCHW -> C8S (module boundary / latents into the synthesis track)
+__global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int HW, int planes) {
+    const size_t total = (size_t)N * planes * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i % HW;
+        const size_t np = i / HW;
+        const int plane = (int)(np % planes);
+        const size_t n = np / planes;
+        f16x8 vh, vl;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = plane * 8 + k;
+            const float v = c < C ? in[(n * C + c) * HW + pix] : 0.0f;
+            _Float16 a, b;
+            split_f16(v, a, b);
+            vh[k] = a;
+            vl[k] = b;
+        }
+        *(f16x8 *)(out + i * 32) = vh;
+        *(f16x8 *)(out + i * 32 + 16) = vl;
+    }
+}
+
+// C8S -> fp32 NCHW (bridges)
+__global__ void c8s_to_nchw_kernel(const char *in, float *out, int N, int C, int HW, int planes) {
+    const size_t total = (size_t)N * C * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i % HW;
+        const size_t nc = i / HW;
+        const int c = (int)(nc % C);
+        const size_t n = nc / C;
+        const _Float16 *rec = (const _Float16 *)(in + ((n * planes + (c >> 3)) * HW + pix) * 32);
+        out[i] = (float)rec[c & 7] + (float)rec[8 + (c & 7)];
+    }
+}
+
 // ---- layout conversions for the split format ------------------------------------------------------
 // fp32 C8 [..][8] -> C8S record [8 hi][8 lo]
 __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t npix) {

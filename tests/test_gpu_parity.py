@@ -22,6 +22,14 @@ CASES = ['noact_small_40x56', 'noact_small_37x45', 'gdn_small_40x56', 'gdn_small
          'gdn_k5bias_48x48', 'gdn_canonical_64x64', 'gdn_canonical_96x80']
 
 
+@pytest.fixture(params=['fp32', 'f16x3'], autouse=True)
+def precision(request, monkeypatch):
+    """Every parity test runs on both arithmetic paths of the conv / GDN contraction: exact fp32 MFMA
+    and the f16x3 split (three f16 MFMAs per product, fp32 accumulate) -- same tolerances."""
+    monkeypatch.setenv('CAE_PRECISION', request.param)
+    return request.param
+
+
 @pytest.fixture(scope='module')
 def cae(built_lib):
     import cnn_autoencoder_amd as cae
