@@ -56,7 +56,7 @@ class CaeError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """Compile libcae_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ['make', '-C', os.path.join(_HERE, 'csrc'), 'all']
+    cmd = ['make', '-j8', '-C', os.path.join(_HERE, 'csrc'), 'all']
     if not verbose:
         cmd.insert(1, '-s')
     subprocess.check_call(cmd)

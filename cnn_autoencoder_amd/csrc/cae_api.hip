@@ -3,6 +3,7 @@
 #include "cae_internal.hpp"
 #include "cae_kernels.hpp"
 #include "cae_kernels_f16.hpp"
+#include "cae_launch.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -22,12 +23,6 @@ int fail(int code, const char *fmt, ...) {
     g_last_error = buf;
     return code;
 }
-
-#define HIP_TRY(expr)                                                                             \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess) return fail(CAE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
-    } while (0)
 
 static int round_ct(int c) {
     const int t = (c + 31) / 32;
@@ -279,286 +274,6 @@ Model::~Model() {
 }
 
 // ---- kernel dispatch ---------------------------------------------------------------------------
-#ifndef CAE_CONV_NW
-#define CAE_CONV_NW 4
-#endif
-#ifndef CAE_DECONV_NW
-#define CAE_DECONV_NW 4
-#endif
-template <int KS, int CT, bool GDN>
-static int launch_conv_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = CAE_CONV_NW;
-    constexpr int WH = 2 * 16 + KS - 2;
-    constexpr int HALO_INSTR = (2 * NW * WH * 2 + 63) / 64;
-    constexpr int CONV_STAGE = KS * CT * 1024 + HALO_INSTR * 1024;
-    constexpr int G_BYTES = GDN ? CT * 4096 : 0;
-#ifdef CAE_EXP_1BLOCK
-    constexpr int LDS = 96 * 1024;
-#else
-    constexpr int LDS = 2 * (CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES);
-#endif
-    auto kern = conv_s2_kernel<KS, CT, NW, GDN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
-    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
-    HIP_TRY(hipGetLastError());
-    return CAE_OK;
-}
-
-template <int KS, int CT, bool GDN>
-static int launch_deconv_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = CAE_DECONV_NW;
-    constexpr int P = KS / 2;
-    constexpr int WH = 32 + (KS - 1 - P) / 2 + (P + 1) / 2;
-    constexpr int HALO_INSTR = (NW * WH * 2 + 63) / 64;
-    constexpr int CONV_STAGE = KS * CT * 1024 + HALO_INSTR * 1024;
-    constexpr int G_BYTES = GDN ? CT * 4096 : 0;
-    constexpr int LDS = 2 * (CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES);
-    auto kern = deconv_s2_kernel<KS, CT, NW, GDN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
-    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
-    HIP_TRY(hipGetLastError());
-    return CAE_OK;
-}
-
-template <int KS, int CT, bool GDN>
-static int launch_first_t(const LayerArgs &a, const FirstArgs &f, hipStream_t st) {
-    constexpr int NW = 4;
-    constexpr int WH = 2 * 16 + KS - 2, HH = 4 * NW + KS - 2;
-    constexpr int LDS = 2 * (GDN ? CT * 4096 : 0) + KS * KS * CT * 512 + ((HH * WH * 16 + 1023) / 1024) * 1024 + 1024;
-    auto kern = conv_first_kernel<KS, CT, NW, GDN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
-    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a, f);
-    HIP_TRY(hipGetLastError());
-    return CAE_OK;
-}
-
-template <int KS>
-static int launch_last_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = 4;
-    constexpr int P = KS / 2;
-    constexpr int NB = (KS - 1 - P) / 2 + (P + 1) / 2 + 1;
-    constexpr int HALO_INSTR = (4 * (NW + NB - 1) * (64 + NB - 1) + 63) / 64;
-    const int lds = 2 * HALO_INSTR * 1024 + NB * NB * a.cci * 1024;
-    auto kern = deconv_last_kernel<KS, NW>;
-    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
-    HIP_TRY(hipGetLastError());
-    return CAE_OK;
-}
-
-template <int KS, int CT, bool GDN>
-static int launch_conv_f16_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = 4;
-    constexpr int WH = 2 * 16 + KS - 2;
-    constexpr int HALO_INSTR = (4 * 16 * WH + 63) / 64;
-    constexpr int CONV_STAGE = KS * CT * 2 * 1024 + HALO_INSTR * 1024;
-    constexpr int G_BYTES = GDN ? CT * 4096 : 0;
-    constexpr int LDS = 2 * (CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES);
-    if constexpr (LDS > 160 * 1024) {
-        return fail(CAE_ERR_UNSUPPORTED, "f16x3: this kernel_size/channel combination exceeds the LDS; use fp32");
-    } else {
-        auto kern = conv_s2_f16_kernel<KS, CT, GDN>;
-        static bool attr_done = false;
-        if (!attr_done) {
-            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            attr_done = true;
-        }
-        const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
-        HIP_TRY(hipGetLastError());
-        return CAE_OK;
-    }
-}
-
-#define DISPATCH_F16(FN, KS_)                                                               \
-    switch (ct) {                                                                          \
-        case 1: return gdn ? FN<KS_, 1, true>(a, st) : FN<KS_, 1, false>(a, st);           \
-        case 2: return gdn ? FN<KS_, 2, true>(a, st) : FN<KS_, 2, false>(a, st);           \
-        case 4: return gdn ? FN<KS_, 4, true>(a, st) : FN<KS_, 4, false>(a, st);           \
-        case 6:                                                                            \
-            if (!gdn) return FN<KS_, 6, false>(a, st);                                     \
-            return fail(CAE_ERR_UNSUPPORTED, "f16x3: GDN with more than 128 channels is not built; use fp32"); \
-        default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct);      \
-    }
-
-int launch_conv_f16(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
-    if (ks == 3) { DISPATCH_F16(launch_conv_f16_t, 3) }
-    if (ks == 5) { DISPATCH_F16(launch_conv_f16_t, 5) }
-    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
-}
-
-template <int KS, int CT, bool GDN>
-static int launch_deconv_f16_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = 8;
-    using G = DeconvGeomF16<KS, CT, NW, GDN>;
-    constexpr int LDS = 2 * G::STAGE_BYTES;
-    if constexpr (LDS > 160 * 1024) {
-        return fail(CAE_ERR_UNSUPPORTED, "f16x3: this kernel_size/channel combination exceeds the LDS; use fp32");
-    } else {
-        auto kern = deconv_s2_f16_kernel<KS, CT, NW, GDN>;
-        static bool attr_done = false;
-        if (!attr_done) {
-            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            attr_done = true;
-        }
-        const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
-        HIP_TRY(hipGetLastError());
-        return CAE_OK;
-    }
-}
-
-int launch_deconv_f16(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
-    if (ks == 3) { DISPATCH_F16(launch_deconv_f16_t, 3) }
-    if (ks == 5) { DISPATCH_F16(launch_deconv_f16_t, 5) }
-    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
-}
-
-template <int KS, int CT, bool GDN>
-static int launch_first_f16_t(const LayerArgs &a, const FirstArgs &f, hipStream_t st) {
-    constexpr int NW = 4;
-    constexpr int WH = 2 * 16 + KS - 2, HH = 4 * NW + KS - 2;
-    constexpr int NS = (KS * KS + 3) / 4;
-    constexpr int LDS = 2 * (GDN ? CT * 4096 : 0) + NS * CT * 2048 + ((HH * WH * 16 + 1023) / 1024) * 1024 + 1024;
-    auto kern = conv_first_f16_kernel<KS, CT, GDN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
-    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a, f);
-    HIP_TRY(hipGetLastError());
-    return CAE_OK;
-}
-
-int launch_first_f16(int ks, int ct, bool gdn, const LayerArgs &a, const FirstArgs &f, hipStream_t st) {
-#define FIRST_F16(KS_)                                                                                       \
-    switch (ct) {                                                                                            \
-        case 1: return gdn ? launch_first_f16_t<KS_, 1, true>(a, f, st) : launch_first_f16_t<KS_, 1, false>(a, f, st); \
-        case 2: return gdn ? launch_first_f16_t<KS_, 2, true>(a, f, st) : launch_first_f16_t<KS_, 2, false>(a, f, st); \
-        case 4: return gdn ? launch_first_f16_t<KS_, 4, true>(a, f, st) : launch_first_f16_t<KS_, 4, false>(a, f, st); \
-        case 6:                                                                                              \
-            if (!gdn) return launch_first_f16_t<KS_, 6, false>(a, f, st);                                    \
-            return fail(CAE_ERR_UNSUPPORTED, "f16x3: GDN with more than 128 channels is not built; use fp32"); \
-        default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct);                       \
-    }
-    if (ks == 3) { FIRST_F16(3) }
-    if (ks == 5) { FIRST_F16(5) }
-    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
-}
-
-template <int KS>
-static int launch_last_f16_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = 4;
-    constexpr int P = KS / 2;
-    constexpr int NB = (KS - 1 - P) / 2 + (P + 1) / 2 + 1;
-    constexpr int HALO_INSTR = (8 * (NW + NB - 1) * (32 + NB - 1) + 63) / 64;
-    const int lds = 2 * HALO_INSTR * 1024 + NB * NB * a.cci * 2048;
-    if (lds > 160 * 1024) return fail(CAE_ERR_UNSUPPORTED, "last-layer weights do not fit the LDS");
-    auto kern = deconv_last_f16_kernel<KS, NW>;
-    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
-    HIP_TRY(hipGetLastError());
-    return CAE_OK;
-}
-
-int launch_last_f16(int ks, const LayerArgs &a, hipStream_t st) {
-    if (ks == 3) return launch_last_f16_t<3>(a, st);
-    if (ks == 5) return launch_last_f16_t<5>(a, st);
-    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
-}
-
-template <int CT, bool INV>
-static int launch_gdn_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = 4;
-    constexpr int LDS = 2 * CT * 4096;
-    auto kern = gdn_c8_kernel<CT, NW, INV>;
-    const int hw = a.H * a.W;
-    const unsigned grid = (unsigned)((size_t)a.N * ((hw + NW * 32 - 1) / (NW * 32)));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
-    HIP_TRY(hipGetLastError());
-    return CAE_OK;
-}
-
-#define DISPATCH_CT(FN, KS_, GDN_)                                               \
-    switch (ct) {                                                                \
-        case 1: return FN<KS_, 1, GDN_>(a, st);                                  \
-        case 2: return FN<KS_, 2, GDN_>(a, st);                                  \
-        case 4: return FN<KS_, 4, GDN_>(a, st);                                  \
-        case 6: return FN<KS_, 6, GDN_>(a, st);                                  \
-        default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct); \
-    }
-
-int launch_conv(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
-    if (ks == 3) {
-        if (gdn) { DISPATCH_CT(launch_conv_t, 3, true) } else { DISPATCH_CT(launch_conv_t, 3, false) }
-    } else if (ks == 5) {
-        if (gdn) { DISPATCH_CT(launch_conv_t, 5, true) } else { DISPATCH_CT(launch_conv_t, 5, false) }
-    }
-    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
-}
-
-#define DISPATCH_CT_F(KS_, GDN_)                                                 \
-    switch (ct) {                                                                \
-        case 1: return launch_first_t<KS_, 1, GDN_>(a, f, st);                   \
-        case 2: return launch_first_t<KS_, 2, GDN_>(a, f, st);                   \
-        case 4: return launch_first_t<KS_, 4, GDN_>(a, f, st);                   \
-        case 6: return launch_first_t<KS_, 6, GDN_>(a, f, st);                   \
-        default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct); \
-    }
-
-int launch_first(int ks, int ct, bool gdn, const LayerArgs &a, const FirstArgs &f, hipStream_t st) {
-    if (ks == 3) {
-        if (gdn) { DISPATCH_CT_F(3, true) } else { DISPATCH_CT_F(3, false) }
-    } else if (ks == 5) {
-        if (gdn) { DISPATCH_CT_F(5, true) } else { DISPATCH_CT_F(5, false) }
-    }
-    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
-}
-
-int launch_last(int ks, const LayerArgs &a, hipStream_t st) {
-    if (ks == 3) return launch_last_t<3>(a, st);
-    if (ks == 5) return launch_last_t<5>(a, st);
-    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
-}
-
-int launch_deconv(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
-    if (ks == 3) {
-        if (gdn) { DISPATCH_CT(launch_deconv_t, 3, true) } else { DISPATCH_CT(launch_deconv_t, 3, false) }
-    } else if (ks == 5) {
-        if (gdn) { DISPATCH_CT(launch_deconv_t, 5, true) } else { DISPATCH_CT(launch_deconv_t, 5, false) }
-    }
-    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
-}
-
-int launch_gdn(int ct, bool inverse, const LayerArgs &a, hipStream_t st) {
-    switch (ct) {
-        case 1: return inverse ? launch_gdn_t<1, true>(a, st) : launch_gdn_t<1, false>(a, st);
-        case 2: return inverse ? launch_gdn_t<2, true>(a, st) : launch_gdn_t<2, false>(a, st);
-        case 4: return inverse ? launch_gdn_t<4, true>(a, st) : launch_gdn_t<4, false>(a, st);
-        case 6: return inverse ? launch_gdn_t<6, true>(a, st) : launch_gdn_t<6, false>(a, st);
-    }
-    return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct);
-}
-
 struct ProfScope {
     Model *m;
     int track;

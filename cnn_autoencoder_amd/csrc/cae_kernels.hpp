@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(NW * 64, CT >= 6 ? 1 : 2) gdn_c8_kernel(const 
 // ---- layout conversion / quantiser kernels (HBM-bound, one element group per thread) ------------
 
 // (n,h,w,c) uint8 -> C8 float / 255   (_autoencoders.py:542-545; true division, as torch does)
-__global__ void u8hwc_to_c8_kernel(const uint8_t *in, float *out, int N, int H, int W, int C, int planes) {
+static __global__ void u8hwc_to_c8_kernel(const uint8_t *in, float *out, int N, int H, int W, int C, int planes) {
     const size_t total = (size_t)N * planes * H * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % ((size_t)H * W);
@@ -788,7 +788,7 @@ __global__ void u8hwc_to_c8_kernel(const uint8_t *in, float *out, int N, int H, 
     }
 }
 
-__global__ void nchw_to_c8_kernel(const float *in, float *out, int N, int C, int HW, int planes) {
+static __global__ void nchw_to_c8_kernel(const float *in, float *out, int N, int C, int HW, int planes) {
     const size_t total = (size_t)N * planes * HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
@@ -808,7 +808,7 @@ __global__ void nchw_to_c8_kernel(const float *in, float *out, int N, int C, int
     }
 }
 
-__global__ void c8_to_nchw_kernel(const float *in, float *out, int N, int C, int HW, int planes) {
+static __global__ void c8_to_nchw_kernel(const float *in, float *out, int N, int C, int HW, int planes) {
     const size_t total = (size_t)N * C * HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
@@ -820,7 +820,7 @@ __global__ void c8_to_nchw_kernel(const float *in, float *out, int N, int C, int
 }
 
 // symbols = int(round_half_even(y - median_c))     (EntropyBottleneck.compress, Appendix A.3)
-__global__ void quantize_kernel(const float *y, const float *medians, int32_t *sym, int C, int HW, size_t total) {
+static __global__ void quantize_kernel(const float *y, const float *medians, int32_t *sym, int C, int HW, size_t total) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)((i / HW) % C);
         sym[i] = (int32_t)rintf(y[i] - medians[c]);
@@ -828,7 +828,7 @@ __global__ void quantize_kernel(const float *y, const float *medians, int32_t *s
 }
 
 // y_hat = float(symbols) + median_c                (EntropyModel.dequantize)
-__global__ void dequantize_kernel(const int32_t *sym, const float *medians, float *y, int C, int HW, size_t total) {
+static __global__ void dequantize_kernel(const int32_t *sym, const float *medians, float *y, int C, int HW, size_t total) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)((i / HW) % C);
         y[i] = (float)sym[i] + medians[c];
@@ -836,7 +836,7 @@ __global__ void dequantize_kernel(const int32_t *sym, const float *medians, floa
 }
 
 // per-tile sum of squared byte differences; one block row per tile, exact integer partial sums
-__global__ void tile_sse_kernel(const uint8_t *a, const uint8_t *b, size_t elems, unsigned long long *out) {
+static __global__ void tile_sse_kernel(const uint8_t *a, const uint8_t *b, size_t elems, unsigned long long *out) {
     const int tile = blockIdx.y;
     const uint8_t *pa = a + (size_t)tile * elems, *pb = b + (size_t)tile * elems;
     unsigned long long acc = 0;
@@ -864,7 +864,7 @@ __global__ void tile_sse_kernel(const uint8_t *a, const uint8_t *b, size_t elems
     if ((threadIdx.x & 63) == 0) atomicAdd(out + tile, acc);
 }
 
-__global__ void u64_to_f64_kernel(const unsigned long long *in, double *out, int n) {
+static __global__ void u64_to_f64_kernel(const unsigned long long *in, double *out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (double)in[i];
 }

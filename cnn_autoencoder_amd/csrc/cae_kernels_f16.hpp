@@ -103,8 +103,13 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&y)[PT][CT], const LayerA
 template <int CT>
 __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
                                                 int h, bool valid) {
+    // (the half-wave exchange below needs both lanes of a pixel: lanes l and l+32 share (oy, ox),
+    //  hence the same `valid`; invalid pairs skip the whole store)
     if (!valid) return;
     if (p.outfmt == OUT_C8) {
+        // lane (px, h) holds channels 4h..4h+3 of every plane as hi (H) and lo (L) halves.  One
+        // v_permlane32_swap per dword leaves the lower lane with [H(ch 0-3) | H(ch 4-7)] and the upper
+        // lane with [L(ch 0-3) | L(ch 4-7)]: one 16-byte store per lane and plane instead of two 8-byte.
         char *out = (char *)p.out;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -119,9 +124,14 @@ __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const L
                     vh[k] = a;
                     vl[k] = b;
                 }
-                char *dst = out + ((((size_t)n * p.out_planes + plane) * p.OH + oy) * p.OW + ox) * 32 + 8 * h;
-                *(f16x4 *)dst = vh;
-                *(f16x4 *)(dst + 16) = vl;
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x2 yh = __builtin_bit_cast(u32x2, vh), xl = __builtin_bit_cast(u32x2, vl);
+                const auto r0 = __builtin_amdgcn_permlane32_swap(yh[0], xl[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(yh[1], xl[1], false, false);
+                const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+                char *dst = out + ((((size_t)n * p.out_planes + plane) * p.OH + oy) * p.OW + ox) * 32 + 16 * h;
+                *(u32x4 *)dst = v;
             }
     } else {
         store_tiles<CT>(acc, p, n, oy, ox, h, valid);
@@ -359,12 +369,13 @@ __global__ void __launch_bounds__(256, 2) conv_first_f16_kernel(const LayerArgs 
 //   accumulator sets (px = 0, 1).  stage = (py, 16-channel chunk q, kernel row ky(py, d)):
 //     weights [kx][ct][hl][64][8 f16]  +  halo [pl][hl][NW rows][WH][16 B]
 // =================================================================================================
-template <int KS, int CT, int NW, bool IGDN>
+template <int KS, int CT, int NW, int PT, bool IGDN>
 struct DeconvGeomF16 {
     static constexpr int P = KS / 2;
     static constexpr int DLO = -((P + 1) / 2), DHI = (KS - 1 - P) / 2;
     static constexpr int WH = 32 + DHI - DLO;
-    static constexpr int PLANE_PIECES = NW * WH;
+    static constexpr int ROWS = NW * PT;  // input rows per block
+    static constexpr int PLANE_PIECES = ROWS * WH;
     static constexpr int HALO_PIECES = 4 * PLANE_PIECES;
     static constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;
     static constexpr int W_INSTR = KS * CT * 2;
@@ -377,10 +388,10 @@ struct DeconvGeomF16 {
     static constexpr int nky(int py) { return (KS - 1 - py - P) / 2 - dmin(py) + 1; }
 };
 
-template <int KS, int CT, int NW, bool IGDN, int PY>
+template <int KS, int CT, int NW, int PT, bool IGDN, int PY>
 __device__ __forceinline__ void deconv_issue_f16(const LayerArgs &p, const char *in_n, size_t plane_bytes, int s,
                                                  char *buf, const int *hrow, const long *hbase, int wave, int lane) {
-    using G = DeconvGeomF16<KS, CT, NW, IGDN>;
+    using G = DeconvGeomF16<KS, CT, NW, PT, IGDN>;
     constexpr int NKY = G::nky(PY);
     const int q = s / NKY, d = G::dmin(PY) + (s - q * NKY);
     const int ky = 2 * d + PY + G::P;
@@ -403,19 +414,22 @@ __device__ __forceinline__ void deconv_issue_f16(const LayerArgs &p, const char 
     }
 }
 
-template <int KS, int CT, int NW, bool IGDN, int PY>
+template <int KS, int CT, int NW, int PT, bool IGDN, int PY>
 __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char *in_n, size_t plane_bytes, char *smem,
                                                  int &sc, const int *hrow, const long *hbase, int wave, int lane,
-                                                 int b_off, int n, int iy, int ix, bool valid) {
-    using G = DeconvGeomF16<KS, CT, NW, IGDN>;
+                                                 int b_off, int n, int iy, int ix) {
+    using G = DeconvGeomF16<KS, CT, NW, PT, IGDN>;
     constexpr int P = G::P;
     constexpr int STAGE_BYTES = G::STAGE_BYTES;
     constexpr int B_HL = G::PLANE_PIECES * 16;
+    constexpr int B_PT = G::WH * 16;  // next input row of this wave
     const int h = lane >> 5;
     const int NS = p.cci * G::nky(PY);
-    f32x16 acc[2][1][CT];  // [px][pt = 1][ct]
-    init_acc<CT>(acc[0][0], p.bias, h, 0.0f);
-    init_acc<CT>(acc[1][0], p.bias, h, 0.0f);
+    f32x16 acc[2][PT][CT];  // [px][row tile][ct]
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) init_acc<CT>(acc[x][pt], p.bias, h, 0.0f);
 
     for (int s = 0; s < NS; ++s) {
         wait_vm0();
@@ -423,11 +437,11 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
         char *cur = smem + (sc & 1) * STAGE_BYTES;
         char *nxt = smem + ((sc + 1) & 1) * STAGE_BYTES;
         if (s + 1 < NS) {
-            deconv_issue_f16<KS, CT, NW, IGDN, PY>(p, in_n, plane_bytes, s + 1, nxt, hrow, hbase, wave, lane);
+            deconv_issue_f16<KS, CT, NW, PT, IGDN, PY>(p, in_n, plane_bytes, s + 1, nxt, hrow, hbase, wave, lane);
         } else if (IGDN) {
             issue_gamma0<CT, NW>(p, nxt, wave, lane);
         } else if (PY == 0) {
-            deconv_issue_f16<KS, CT, NW, IGDN, 1>(p, in_n, plane_bytes, 0, nxt, hrow, hbase, wave, lane);
+            deconv_issue_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, 0, nxt, hrow, hbase, wave, lane);
         }
         const char *wb = cur + lane * 16;
         const char *hb = cur + b_off;
@@ -435,39 +449,59 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
         for (int kx = 0; kx < KS; ++kx) {
             const int px = (kx + P) & 1;
             const int dx = (kx - P - px) / 2;
-            const f16x8 bh = *(const f16x8 *)(hb - dx * 16);
-            const f16x8 bl = *(const f16x8 *)(hb - dx * 16 + B_HL);
+            f16x8 bh[PT], bl[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                bh[pt] = *(const f16x8 *)(hb + pt * B_PT - dx * 16);
+                bl[pt] = *(const f16x8 *)(hb + pt * B_PT - dx * 16 + B_HL);
+            }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const f16x8 ah = *(const f16x8 *)(wb + ((kx * CT + ct) * 2 + 0) * 1024);
                 const f16x8 al = *(const f16x8 *)(wb + ((kx * CT + ct) * 2 + 1) * 1024);
-                if (px == 0)
-                    acc[0][0][ct] = mfma3(ah, al, bh, bl, acc[0][0][ct]);
-                else
-                    acc[1][0][ct] = mfma3(ah, al, bh, bl, acc[1][0][ct]);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    if (px == 0)
+                        acc[0][pt][ct] = mfma3(ah, al, bh[pt], bl[pt], acc[0][pt][ct]);
+                    else
+                        acc[1][pt][ct] = mfma3(ah, al, bh[pt], bl[pt], acc[1][pt][ct]);
+                }
             }
         }
         ++sc;
     }
 
+    auto store_px = [&](int x) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+            store_tiles_f16<CT>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h, (iy + pt) < p.H && ix < p.W);
+    };
     if constexpr (IGDN) {
-        gdn_stages_f16<CT, 1, NW, true, STAGE_BYTES>(acc[0], p, smem, sc, wave, lane,
-                                                     [&](char *nxt) { issue_gamma0<CT, NW>(p, nxt, wave, lane); });
-        store_tiles_f16<CT>(acc[0][0], p, n, 2 * iy + PY, 2 * ix, h, valid);
-        gdn_stages_f16<CT, 1, NW, true, STAGE_BYTES>(acc[1], p, smem, sc, wave, lane, [&](char *nxt) {
-            if (PY == 0)
-                deconv_issue_f16<KS, CT, NW, IGDN, 1>(p, in_n, plane_bytes, 0, nxt, hrow, hbase, wave, lane);
+        // one (px, row tile) at a time: 64 norm accumulators live instead of 128 (register budget);
+        // gamma is re-streamed per tile (L2-resident, 64 KiB)
+        static_for<2 * PT>([&](auto it) {
+            constexpr int idx = decltype(it)::value;
+            constexpr int x = idx / PT, pt = idx % PT;
+            f32x16(&tile)[1][CT] = *reinterpret_cast<f32x16(*)[1][CT]>(&acc[x][pt]);
+            gdn_stages_f16<CT, 1, NW, true, STAGE_BYTES>(tile, p, smem, sc, wave, lane, [&](char *nxt) {
+                if constexpr (idx + 1 < 2 * PT) {
+                    issue_gamma0<CT, NW>(p, nxt, wave, lane);
+                } else if (PY == 0) {
+                    deconv_issue_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, 0, nxt, hrow, hbase, wave, lane);
+                }
+            });
+            store_tiles_f16<CT>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h, (iy + pt) < p.H && ix < p.W);
         });
-        store_tiles_f16<CT>(acc[1][0], p, n, 2 * iy + PY, 2 * ix + 1, h, valid);
     } else {
-        store_tiles_f16<CT>(acc[0][0], p, n, 2 * iy + PY, 2 * ix, h, valid);
-        store_tiles_f16<CT>(acc[1][0], p, n, 2 * iy + PY, 2 * ix + 1, h, valid);
+        store_px(0);
+        store_px(1);
     }
 }
 
-template <int KS, int CT, int NW, bool IGDN>
-__global__ void __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) deconv_s2_f16_kernel(const LayerArgs p) {
-    using G = DeconvGeomF16<KS, CT, NW, IGDN>;
+// PT input rows per wave: PT = 2 halves the LDS bytes read per MFMA (4 fat waves, one block per CU)
+template <int KS, int CT, int NW, int PT, bool IGDN>
+__global__ void __launch_bounds__(NW * 64, 1) deconv_s2_f16_kernel(const LayerArgs p) {
+    using G = DeconvGeomF16<KS, CT, NW, PT, IGDN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -477,7 +511,7 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) deconv_s2_f16_kernel
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
     const int n = bid / p.tiles_y;
-    const int iy0 = ty * NW, ix0 = tx * 32;
+    const int iy0 = ty * G::ROWS, ix0 = tx * 32;
 
     int hrow[G::MAXP];
     long hbase[G::MAXP];  // byte offset of (plane-in-chunk, half, column) inside the chunk, < 0: outside
@@ -496,16 +530,15 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) deconv_s2_f16_kernel
     }
     const size_t plane_bytes = (size_t)p.H * p.W * 32;
     const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
-    // B operand: halo [pl = h][hl][row = wave][x = m + DHI - dx]
-    const int b_off = G::W_BYTES + (((2 * h) * NW + wave) * G::WH + m + G::DHI) * 16;
-    const int iy = iy0 + wave, ix = ix0 + m;
-    const bool valid = iy < p.H && ix < p.W;
+    // B operand: halo [pl = h][hl][row = PT*wave + pt][x = m + DHI - dx]
+    const int b_off = G::W_BYTES + (((2 * h) * G::ROWS + PT * wave) * G::WH + m + G::DHI) * 16;
+    const int iy = iy0 + PT * wave, ix = ix0 + m;
     int sc = 0;
-    deconv_issue_f16<KS, CT, NW, IGDN, 0>(p, in_n, plane_bytes, 0, smem, hrow, hbase, wave, lane);
-    deconv_phase_f16<KS, CT, NW, IGDN, 0>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, n, iy, ix,
-                                          valid);
-    deconv_phase_f16<KS, CT, NW, IGDN, 1>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, n, iy, ix,
-                                          valid);
+    deconv_issue_f16<KS, CT, NW, PT, IGDN, 0>(p, in_n, plane_bytes, 0, smem, hrow, hbase, wave, lane);
+    deconv_phase_f16<KS, CT, NW, PT, IGDN, 0>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, n, iy,
+                                              ix);
+    deconv_phase_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, n, iy,
+                                              ix);
 }
 
 // =================================================================================================
@@ -623,7 +656,7 @@ __global__ void __launch_bounds__(NW * 64, 2) deconv_last_f16_kernel(const Layer
 }
 
 // fp32 NCHW -> C8S (module boundary / latents into the synthesis track)
-__global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int HW, int planes) {
+static __global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int HW, int planes) {
     const size_t total = (size_t)N * planes * HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
@@ -646,7 +679,7 @@ __global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int
 }
 
 // C8S -> fp32 NCHW (bridges)
-__global__ void c8s_to_nchw_kernel(const char *in, float *out, int N, int C, int HW, int planes) {
+static __global__ void c8s_to_nchw_kernel(const char *in, float *out, int N, int C, int HW, int planes) {
     const size_t total = (size_t)N * C * HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
@@ -660,7 +693,7 @@ __global__ void c8s_to_nchw_kernel(const char *in, float *out, int N, int C, int
 
 // ---- layout conversions for the split format ------------------------------------------------------
 // fp32 C8 [..][8] -> C8S record [8 hi][8 lo]
-__global__ void c8_to_c8s_kernel(const float *in, char *out, size_t npix) {
+static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t npix) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
         const f32x4 a = *(const f32x4 *)(in + i * 8), b = *(const f32x4 *)(in + i * 8 + 4);
         f16x8 vh, vl;
@@ -679,7 +712,7 @@ __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t npix) {
     }
 }
 
-__global__ void c8s_to_c8_kernel(const char *in, float *out, size_t npix) {
+static __global__ void c8s_to_c8_kernel(const char *in, float *out, size_t npix) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
         const f16x8 vh = *(const f16x8 *)(in + i * 32), vl = *(const f16x8 *)(in + i * 32 + 16);
         f32x4 a, b;
