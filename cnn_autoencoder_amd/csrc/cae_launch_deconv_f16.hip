@@ -7,7 +7,9 @@
 namespace cae {
 template <int KS, int CT, bool GDN>
 static int launch_deconv_f16_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = 4, PT = 2;
+    // 8 waves x 1 input row measured faster than 4 waves x 2 rows (register spills at 512 VGPRs):
+    // profiles/r01_experiments.md
+    constexpr int NW = 8, PT = 1;
     using G = DeconvGeomF16<KS, CT, NW, PT, GDN>;
     constexpr int LDS = 2 * G::STAGE_BYTES;
     if constexpr (LDS > 160 * 1024) {

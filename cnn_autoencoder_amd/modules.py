@@ -158,9 +158,11 @@ class _Track(nn.Module):
                     mod._owner = (ref, i)
 
     def precision_code(self) -> int:
-        """0 = exact fp32 MFMA, 1 = f16x3 split MFMA (attribute `precision`, default from CAE_PRECISION)."""
+        """0 = exact fp32 MFMA, 1 = f16x3 split MFMA.  Attribute `precision` ('fp32' | 'f16x3'), else the
+        CAE_PRECISION environment variable, else 'f16x3' (fp32-class accuracy at ~2x the throughput;
+        channel counts the f16x3 kernels do not cover need precision='fp32')."""
         import os
-        prec = getattr(self, 'precision', None) or os.environ.get('CAE_PRECISION', 'fp32')
+        prec = getattr(self, 'precision', None) or os.environ.get('CAE_PRECISION', 'f16x3')
         if prec not in ('fp32', 'f16x3'):
             raise ValueError(f"precision must be 'fp32' or 'f16x3', got {prec!r}")
         return 1 if prec == 'f16x3' else 0

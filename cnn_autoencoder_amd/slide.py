@@ -172,15 +172,18 @@ class SlideCoder:
             sym.record_stream(copy)
             return k, pin, done, hw
 
-        def host_code(k, pin, done, hw):
+        def host_encode(k, pin, done, hw):
             done.synchronize()
             t0 = time.perf_counter()
             payloads = self.eb.encode_symbols(pin.numpy(), self.coder_threads)
+            return k, payloads, hw, pin.shape, time.perf_counter() - t0
+
+        def host_decode(enc_future):
+            k, payloads, hw, shape, te = enc_future.result()
             t1 = time.perf_counter()
-            back = self._pin(('d', k % 3), pin.shape, torch.int32)  # decode straight into pinned memory
+            back = self._pin(('d', k % 3), shape, torch.int32)  # decode straight into pinned memory
             self.eb.decode_symbols(payloads, hw, self.coder_threads, out=back.numpy())
-            t2 = time.perf_counter()
-            return payloads, back, t1 - t0, t2 - t1
+            return payloads, back, te, time.perf_counter() - t1
 
         def stage_d(k, payloads, back):
             t = batches[k]
@@ -199,13 +202,18 @@ class SlideCoder:
 
         pending = []  # (sse tensor on GPU, nbytes list, samples)
         DEPTH = 2  # analysis runs DEPTH batches ahead of synthesis: the host always has a batch to code
-        with ThreadPoolExecutor(max_workers=1) as pool:
+        # two host workers: batch k+1 is range-encoded while batch k is decoded
+        with ThreadPoolExecutor(max_workers=1) as enc_pool, ThreadPoolExecutor(max_workers=1) as dec_pool:
             futs = {}
+
+            def submit(k):
+                futs[k] = dec_pool.submit(host_decode, enc_pool.submit(host_encode, *stage_a(k)))
+
             for k in range(min(DEPTH, K)):
-                futs[k] = pool.submit(host_code, *stage_a(k))
+                submit(k)
             for k in range(K):
                 if k + DEPTH < K:
-                    futs[k + DEPTH] = pool.submit(host_code, *stage_a(k + DEPTH))
+                    submit(k + DEPTH)
                 t0 = time.perf_counter()
                 payloads, back, te, td = futs.pop(k).result()
                 tm['wait_host'] += time.perf_counter() - t0
