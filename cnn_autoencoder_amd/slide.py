@@ -149,8 +149,10 @@ class SlideCoder:
         dev = batches[0].device
         main = torch.cuda.current_stream(dev)
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(dev)
-        copy = self._copy_stream
+            # one side stream per direction: a D2H queued behind a not-yet-finished analysis must not hold
+            # back the H2D the next synthesis is waiting for
+            self._copy_stream = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        copy, copy_up = self._copy_stream
         K = len(batches)
         tm = dict(host_encode=0.0, host_decode=0.0, wait_host=0.0)
         all_payloads, stats_parts = [], []
@@ -188,10 +190,10 @@ class SlideCoder:
         def stage_d(k, payloads, back):
             t = batches[k]
             n, h, w, c = t.shape
-            with torch.cuda.stream(copy):  # H2D beside the kernels of the main stream
+            with torch.cuda.stream(copy_up):  # H2D beside the kernels of the main stream
                 sym = back.to(dev, non_blocking=True)
                 up = torch.cuda.Event()
-                up.record(copy)
+                up.record(copy_up)
             main.wait_event(up)
             sym.record_stream(main)
             lh, lw = h // 2 ** self.level, w // 2 ** self.level
