@@ -99,7 +99,7 @@ def cpu_baseline(state, cfg, tiles, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--steps', type=int, default=32)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--tile', type=int, default=1024)
     ap.add_argument('--batch', type=int, default=32, help='tiles per step per GPU')
@@ -191,9 +191,12 @@ def main():
         # the gfx950 correction); only valid for the profiled shape (batch 32, 1024x1024 tiles)
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['kernels']
-            key = {'analysis.1': 'conv_s2_kernel<3, 4, 4, true>@4194304',
-                   'synthesis.2': 'deconv_s2_kernel<3, 4, 4, true>@4194304'}.get(dom[0].split(' ')[0])
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))[args.precision]
+            keys = {'fp32': {'analysis.1': 'conv_s2_kernel<3, 4, 4, true>@4194304',
+                             'synthesis.2': 'deconv_s2_kernel<3, 4, 4, true>@4194304'},
+                    'f16x3': {'analysis.1': 'conv_s2_f16_kernel<3, 4, true>@2097152',
+                              'synthesis.2': 'deconv_s2_f16_kernel<3, 4, 8, 1, true>@4194304'}}[args.precision]
+            key = keys.get(dom[0].split(' ')[0])
             if key and B == 32 and H == 1024:
                 traffic = tj[key]['hbm_mb'] * 1e6
         except Exception:
