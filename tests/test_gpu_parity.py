@@ -262,3 +262,60 @@ def test_pipelined_run_equals_simple_roundtrip(cae):
     assert torch.equal(stats, torch.cat([r[2] for r in ref]))
     s = slide.slide_summary(slide.gather_stats(stats), 64 * 96)
     assert s['tiles'] == 9 and s['bpp'] > 0 and np.isfinite(s['psnr'])
+
+
+def _canonical_codec(cae, fit=True, seed=0):
+    from cnn_autoencoder_amd import synth
+    from oracle import cae_oracle as O
+    state = synth.synthetic_state(synth.CANONICAL, seed=seed)
+    codec = cae.ConvolutionalAutoencoder(checkpoint=state)
+    eb = codec._model['fact_ent'].module
+    if fit:
+        eb.fit_quantiles()
+        eb.update(force=True)
+    o = O.EntropyBottleneckOracle(192)
+    o.load({k: v.cpu() for k, v in eb.state_dict().items()})
+    o.update()
+    assert torch.equal(o._quantized_cdf, eb._quantized_cdf.cpu())
+    return codec, state, o
+
+
+def test_cfg2_batch32_256_psnr_bpp_vs_cpu_reference(cae):
+    """BASELINE config 2: synthetic 256x256x3 tiles, batch 32, analysis+synthesis on one MI355X; PSNR / bpp
+    against the CPU oracle's own compress -> decompress of the same tiles (4 of them, to bound CPU time)."""
+    from cnn_autoencoder_amd import slide, synth
+    from oracle import c_oracle as C
+    from oracle import cae_oracle as O
+    codec, state, o = _canonical_codec(cae)
+    tiles = np.concatenate([synth.histo_tiles(4, 256), synth.uniform_tiles(28, 256)])
+    coder = slide.SlideCoder(codec)
+    stats, payloads = coder.run([torch.from_numpy(tiles).cuda()], keep_payloads=True)
+    enc_l, dec_l = oracle_layers(state, 'encoder'), oracle_layers(state, 'decoder')
+    for i in range(4):
+        buf = O.codec_encode(tiles[i], enc_l, o, C.rans_encode_with_indexes)
+        rec = O.codec_decode(buf, dec_l, o, C.rans_decode_with_indexes)
+        sse_ref = float(((rec.astype(np.float64) - tiles[i]) ** 2).sum())
+        bpp_ref, bpp_gpu = 8 * len(buf) / 256 ** 2, 8 * float(stats[i, 0]) / 256 ** 2
+        psnr = lambda sse: 10 * np.log10(255.0 ** 2 / (sse / tiles[i].size))
+        assert abs(bpp_gpu - bpp_ref) <= 2e-3 * bpp_ref + 1e-3, (bpp_gpu, bpp_ref)
+        assert abs(psnr(float(stats[i, 1])) - psnr(sse_ref)) < 1e-3
+    assert stats.shape == (32, 3)
+
+
+def test_cfg3_batch128_256_bitstreams_bit_exact(cae):
+    """BASELINE config 3: 128 x 256x256 tiles, full entropy-coded bitstreams on one MI355X, bit-exact against
+    the oracle coder on the same latents; the decoder inverts every stream exactly."""
+    from cnn_autoencoder_amd import synth
+    from oracle import c_oracle as C
+    codec, state, o = _canonical_codec(cae, fit=False)
+    tiles = np.concatenate([synth.histo_tiles(8, 256, first_index=100), synth.uniform_tiles(120, 256, seed=5)])
+    bufs = codec.encode_batch(tiles)
+    y = codec._model['encoder'].module.forward_u8(torch.from_numpy(tiles).cuda()).cpu()
+    ref = o.compress(y, C.rans_encode_with_indexes)
+    assert [b[16:] for b in bufs] == ref
+    assert all(struct.unpack('>QQ', b[:16]) == (256, 256) for b in bufs)
+    eb = codec._model['fact_ent'].module
+    sym = eb.decode_symbols([b[16:] for b in bufs], 16 * 16)
+    assert np.array_equal(sym.reshape(128, 192, 16, 16), o.symbols(y).numpy())
+    rec = codec.decode_batch(bufs)
+    assert rec.shape == (128, 256, 256, 3)
