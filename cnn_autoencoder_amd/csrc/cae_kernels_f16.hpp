@@ -40,11 +40,13 @@ __device__ __forceinline__ f32x16 mfma3(const f16x8 &ah, const f16x8 &al, const 
 // packed gamma: [jt][co][s(2)][hl(2)][64 lanes][8 f16]:
 //   G(c = 32co + (lane&31), j = 32jt + row(8s + e) + 4(lane>>5)),  row(r) = (r&3) + 8(r>>2)
 // (the k order inside a 16-deep step is the accumulator's own row order, so y*y needs no shuffle).
-template <int CT, int PT, int NW, bool INVERSE, int STAGE_BYTES, class Tail>
-__device__ __forceinline__ void gdn_stages_f16(f32x16 (&y)[PT][CT], const LayerArgs &p, char *smem, int &sc,
+template <int CT, int PTA, int NW, bool INVERSE, int STAGE_BYTES, int PT0 = 0, int PT = PTA, class Tail>
+__device__ __forceinline__ void gdn_stages_f16(f32x16 (&yy)[PTA][CT], const LayerArgs &p, char *smem, int &sc,
                                                int wave, int lane, Tail tail) {
+    // normalises the row tiles PT0 .. PT0+PT-1 of yy (the others are left untouched)
     constexpr int G_BYTES = CT * 4096;  // per jt: CT co x 2 s x 2 hl x 1 KiB
     const int h = lane >> 5;
+    f32x16(&y)[PTA][CT] = yy;
     f32x16 nrm[PT][CT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) init_acc<CT>(nrm[pt], p.beta, h, 1.0f);
@@ -72,7 +74,7 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&y)[PT][CT], const LayerA
             for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v = y[pt][jt][8 * s + e];
+                    const float v = y[PT0 + pt][jt][8 * s + e];
                     _Float16 a, b;
                     split_f16(v * v, a, b);
                     sh[pt][e] = a;
@@ -95,7 +97,7 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&y)[PT][CT], const LayerA
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float nv = nrm[pt][ct][r];
-                y[pt][ct][r] *= INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv);
+                y[PT0 + pt][ct][r] *= INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv);
             }
 }
 
@@ -447,6 +449,7 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
         const char *hb = cur + b_off;
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
+            if (PT > 1) __builtin_amdgcn_sched_barrier(0);  // bound operand live ranges to one tap (register budget)
             const int px = (kx + P) & 1;
             const int dx = (kx - P - px) / 2;
             f16x8 bh[PT], bl[PT];
@@ -482,8 +485,7 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
         static_for<2 * PT>([&](auto it) {
             constexpr int idx = decltype(it)::value;
             constexpr int x = idx / PT, pt = idx % PT;
-            f32x16(&tile)[1][CT] = *reinterpret_cast<f32x16(*)[1][CT]>(&acc[x][pt]);
-            gdn_stages_f16<CT, 1, NW, true, STAGE_BYTES>(tile, p, smem, sc, wave, lane, [&](char *nxt) {
+            gdn_stages_f16<CT, PT, NW, true, STAGE_BYTES, pt, 1>(acc[x], p, smem, sc, wave, lane, [&](char *nxt) {
                 if constexpr (idx + 1 < 2 * PT) {
                     issue_gamma0<CT, NW>(p, nxt, wave, lane);
                 } else if (PY == 0) {
