@@ -31,6 +31,7 @@ SYMBOLS = {
     'cae_model_create': (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     'cae_model_destroy': (None, [c_void_p]),
     'cae_model_set_layer': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cae_model_set_layer_act': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_model_set_precision': (c_int, [c_void_p, c_int]),
     'cae_model_set_entropy': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cae_analysis': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -35,7 +35,8 @@ static int round_ct(int c) {
 
 // ---- packing -----------------------------------------------------------------------------------
 // weights -> [chunk][ky][kx][ct][lane][j]:  value W(cout = 32ct + (lane&31), cin = 8chunk + 4(lane>>5) + j, ky, kx)
-static std::vector<float> pack_weights(const float *w, bool transposed, int cin, int cout, int ks, int ct) {
+static std::vector<float> pack_weights(const float *w, bool transposed, int cin, int cout, int ks, int ct,
+                                       bool flip = false) {
     const int chunks = (cin + 7) / 8;
     std::vector<float> out((size_t)chunks * ks * ks * ct * 256, 0.0f);
     size_t o = 0;
@@ -49,8 +50,9 @@ static std::vector<float> pack_weights(const float *w, bool transposed, int cin,
                             const int ci = 8 * c + 4 * (lane >> 5) + j;
                             if (co < cout && ci < cin) {
                                 // conv: (cout,cin,k,k); transposed conv: (cin,cout,k,k)
-                                const size_t idx = transposed ? (((size_t)ci * cout + co) * ks + ky) * ks + kx
-                                                              : (((size_t)co * cin + ci) * ks + ky) * ks + kx;
+                                const int sy = flip ? ks - 1 - ky : ky, sx = flip ? ks - 1 - kx : kx;
+                                const size_t idx = transposed ? (((size_t)ci * cout + co) * ks + sy) * ks + sx
+                                                              : (((size_t)co * cin + ci) * ks + sy) * ks + sx;
                                 out[o] = w[idx];
                             }
                         }
@@ -261,6 +263,8 @@ Model::~Model() {
             if (l.gp) (void)hipFree(l.gp);
             if (l.beta) (void)hipFree(l.beta);
             if (l.wp_edge) (void)hipFree(l.wp_edge);
+            if (l.pre_wp) (void)hipFree(l.pre_wp);
+            if (l.pre_bias) (void)hipFree(l.pre_bias);
             if (l.wp16) (void)hipFree(l.wp16);
             if (l.gp16) (void)hipFree(l.gp16);
             if (l.wp_edge16) (void)hipFree(l.wp_edge16);
@@ -410,6 +414,50 @@ int cae_model_set_layer(cae_model_t *mm, int track, int index, int cin, int cout
     return CAE_OK;
 }
 
+int cae_model_set_layer_act(cae_model_t *mm, int track, int index, int act, const float *pre_w, const float *pre_b) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m) return fail(CAE_ERR_ARG, "NULL model");
+    if (track != CAE_ANALYSIS && track != CAE_SYNTHESIS) return fail(CAE_ERR_ARG, "bad track %d", track);
+    if (index < 0 || index >= m->L) return fail(CAE_ERR_ARG, "layer index %d out of range", index);
+    if (act < 0 || act > 2) return fail(CAE_ERR_ARG, "bad activation %d", act);
+    std::lock_guard<std::mutex> lk(m->mu);
+    Layer &l = (track == CAE_ANALYSIS ? m->enc : m->dec)[index];
+    if (!l.set) return fail(CAE_ERR_ARG, "set the layer before its activation");
+    if (l.gdn && (act != 0 || pre_w)) return fail(CAE_ERR_ARG, "a GDN unit has no other activation");
+    if ((act != 0 || pre_w) && m->precision != 0)
+        return fail(CAE_ERR_UNSUPPORTED, "LeakyReLU / ReLU units run on the fp32 path: set precision 0");
+    if (pre_b && !pre_w) return fail(CAE_ERR_ARG, "pre-convolution bias without weight");
+    l.act = act;
+    if (l.pre_wp) {
+        (void)hipFree(l.pre_wp);
+        l.pre_wp = nullptr;
+    }
+    if (l.pre_bias) {
+        (void)hipFree(l.pre_bias);
+        l.pre_bias = nullptr;
+    }
+    if (pre_w) {
+        const int ctin = round_ct(l.cin);
+        if (ctin < 0) return fail(CAE_ERR_UNSUPPORTED, "more than 192 channels not supported");
+        // synthesis: ConvTranspose2d(stride 1, padding k//2) == zero-padded correlation with the flipped kernel
+        const bool tr = track == CAE_SYNTHESIS;
+        int rc = upload(pack_weights(pre_w, tr, l.cin, l.cin, m->ks, ctin, tr), &l.pre_wp);
+        if (rc) return rc;
+        if (pre_b) {
+            std::vector<float> b(ctin * 32, 0.0f);
+            std::copy(pre_b, pre_b + l.cin, b.begin());
+            if ((rc = upload(b, &l.pre_bias))) return rc;
+        }
+        if (l.wp_edge) {  // the fused first-layer kernel reads the raw tile; a pre-convolution sits in between
+            if (track == CAE_ANALYSIS) {
+                (void)hipFree(l.wp_edge);
+                l.wp_edge = nullptr;
+            }
+        }
+    }
+    return CAE_OK;
+}
+
 int cae_model_set_precision(cae_model_t *mm, int precision) {
     Model *m = reinterpret_cast<Model *>(mm);
     if (!m) return fail(CAE_ERR_ARG, "NULL model");
@@ -461,10 +509,12 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
     size_t maxact = 0;
     {
         int ch = h, cw = w;
-        for (int i = 0; i + 1 < m->L; ++i) {
+        for (int i = 0; i < m->L; ++i) {
+            if (m->enc[i].pre_wp)  // stride-1 pre-convolution: same size, cin channels
+                maxact = std::max(maxact, (size_t)n * round_ct(m->enc[i].cin) * 4 * ch * cw * 32);
             ch = (ch + 1) / 2;
             cw = (cw + 1) / 2;
-            maxact = std::max(maxact, (size_t)n * m->enc[i].ct * 4 * ch * cw * 32);
+            if (i + 1 < m->L) maxact = std::max(maxact, (size_t)n * m->enc[i].ct * 4 * ch * cw * 32);
         }
     }
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
@@ -498,12 +548,40 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
 
     const float *cur = (const float *)m->ws[0];
     int cur_planes = p0, ch = h, cw = w;
+    int flip = 0;  // which of ws[1] / ws[2] receives the next intermediate
     for (int i = 0; i < m->L; ++i) {
         const Layer &l = m->enc[i];
         const bool last = i == m->L - 1;
+        if (l.pre_wp) {  // Conv2d(cin, cin, k, stride 1, reflect) + activation  (_autoencoders.py:62-76)
+            LayerArgs b{};
+            const int ctin = round_ct(l.cin);
+            b.in = cur;
+            b.out = m->ws[1 + flip];
+            b.wp = l.pre_wp;
+            b.bias = l.pre_bias;
+            b.zero = m->zero;
+            b.N = n;
+            b.H = ch;
+            b.W = cw;
+            b.OH = ch;
+            b.OW = cw;
+            b.in_planes = cur_planes;
+            b.cci = l.chunks;
+            b.out_planes = ctin * 4;
+            b.cout = l.cin;
+            b.tiles_x = (cw + 15) / 16;
+            b.tiles_y = (ch + 2 * CAE_CONV_NW - 1) / (2 * CAE_CONV_NW);
+            b.outfmt = OUT_C8;
+            b.act = l.act;
+            if ((rc = launch_conv_s1(m->ks, ctin, false, b, st))) return rc;
+            cur = (const float *)b.out;
+            cur_planes = ctin * 4;
+            flip ^= 1;
+        }
         LayerArgs a{};
         a.in = cur;
-        a.out = last ? (void *)latents : m->ws[1 + (i & 1)];
+        a.out = last ? (void *)latents : m->ws[1 + flip];
+        a.act = l.act;
         a.wp = l.wp;
         a.bias = l.bias;
         a.gp = l.gp;
@@ -547,6 +625,7 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
         cur_planes = l.ct * 4;
         ch = a.OH;
         cw = a.OW;
+        flip ^= 1;
     }
     return CAE_OK;
 }
@@ -571,10 +650,12 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
     size_t maxact = 0;
     {
         int ch = lh, cw = lw;
-        for (int i = 0; i + 1 < m->L; ++i) {
+        for (int i = 0; i < m->L; ++i) {
+            if (m->dec[i].pre_wp)
+                maxact = std::max(maxact, (size_t)n * round_ct(m->dec[i].cin) * 4 * ch * cw * 32);
             ch *= 2;
             cw *= 2;
-            maxact = std::max(maxact, (size_t)n * m->dec[i].ct * 4 * ch * cw * 32);
+            if (i + 1 < m->L) maxact = std::max(maxact, (size_t)n * m->dec[i].ct * 4 * ch * cw * 32);
         }
     }
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
@@ -594,12 +675,40 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
 
     const float *cur = (const float *)m->ws[0];
     int cur_planes = p0, ch = lh, cw = lw;
+    int flip = 0;
     for (int i = 0; i < m->L; ++i) {
         const Layer &l = m->dec[i];
         const bool last = i == m->L - 1;
+        if (l.pre_wp) {  // ConvTranspose2d(cin, cin, k, stride 1, padding k//2) + activation (_autoencoders.py:187-202)
+            LayerArgs b{};
+            const int ctin = round_ct(l.cin);
+            b.in = cur;
+            b.out = m->ws[1 + flip];
+            b.wp = l.pre_wp;
+            b.bias = l.pre_bias;
+            b.zero = m->zero;
+            b.N = n;
+            b.H = ch;
+            b.W = cw;
+            b.OH = ch;
+            b.OW = cw;
+            b.in_planes = cur_planes;
+            b.cci = l.chunks;
+            b.out_planes = ctin * 4;
+            b.cout = l.cin;
+            b.tiles_x = (cw + 15) / 16;
+            b.tiles_y = (ch + 2 * CAE_CONV_NW - 1) / (2 * CAE_CONV_NW);
+            b.outfmt = OUT_C8;
+            b.act = l.act;
+            if ((rc = launch_conv_s1(m->ks, ctin, true, b, st))) return rc;
+            cur = (const float *)b.out;
+            cur_planes = ctin * 4;
+            flip ^= 1;
+        }
         LayerArgs a{};
         a.in = cur;
-        a.out = last ? out : m->ws[1 + (i & 1)];
+        a.out = last ? out : m->ws[1 + flip];
+        a.act = l.act;
         a.wp = l.wp;
         a.bias = l.bias;
         a.gp = l.gp;
@@ -656,6 +765,7 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
         cur_planes = l.ct * 4;
         ch = a.OH;
         cw = a.OW;
+        flip ^= 1;
     }
     return CAE_OK;
 }

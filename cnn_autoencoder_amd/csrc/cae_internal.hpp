@@ -20,6 +20,10 @@ struct Layer {
     float *gp = nullptr;    // packed gamma (device)
     float *beta = nullptr;  // [ct*32] (device)
     float *wp_edge = nullptr;  // packed weights of the specialised first-conv / last-deconv kernel, or null
+    // LeakyReLU / ReLU units: stride-1 convolution (cin -> cin) + activation in front of the strided one
+    float *pre_wp = nullptr;   // packed weights of the pre-convolution, or null
+    float *pre_bias = nullptr;
+    int act = 0;               // activation after the pre-convolution and after this layer (0 none, 1 LeakyReLU, 2 ReLU)
     void *wp16 = nullptr;      // f16x3 path: packed hi/lo weights
     void *gp16 = nullptr;      // f16x3 path: packed hi/lo gamma
     void *wp_edge16 = nullptr; // f16x3 path: packed weights of the first-conv / last-deconv kernel

@@ -51,6 +51,7 @@ struct LayerArgs {
     int cout;           // real number of output channels (NCHW / U8 epilogues)
     int tiles_x, tiles_y;
     int outfmt;
+    int act;            // epilogue activation: 0 none, 1 LeakyReLU(0.01), 2 ReLU (nn.LeakyReLU / nn.ReLU defaults)
 };
 
 // compile-time unrolled loop: f(std::integral_constant<int, I>{}) for I = 0..N-1
@@ -163,6 +164,11 @@ __device__ __forceinline__ void issue_gamma0(const LayerArgs &p, char *buf, int 
     }
 }
 
+__device__ __forceinline__ float apply_act(float v, int act) {
+    // _define_act_layer (_autoencoders.py:19-34): nn.LeakyReLU() has negative_slope 0.01
+    return act == 0 ? v : (act == 1 ? (v > 0.0f ? v : 0.01f * v) : (v > 0.0f ? v : 0.0f));
+}
+
 // ---- epilogue store of CT accumulator tiles ---------------------------------------------------
 // (oy, ox): this lane's output pixel; valid: inside the image.
 template <int CT>
@@ -177,7 +183,8 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const Layer
             for (int g = 0; g < 4; ++g) {
                 const int plane = 4 * ct + g;
                 if (plane < p.out_planes) {
-                    f32x4 v = {acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
+                    f32x4 v = {apply_act(acc[ct][4 * g], p.act), apply_act(acc[ct][4 * g + 1], p.act),
+                               apply_act(acc[ct][4 * g + 2], p.act), apply_act(acc[ct][4 * g + 3], p.act)};
                     float *dst = out + ((((size_t)n * p.out_planes + plane) * p.OH + oy) * p.OW + ox) * 8 + 4 * h;
                     *(f32x4 *)dst = v;
                 }
@@ -189,7 +196,7 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const Layer
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = 32 * ct + acc_row(r) + 4 * h;
-                if (c < p.cout) out[(((size_t)n * p.cout + c) * p.OH + oy) * p.OW + ox] = acc[ct][r];
+                if (c < p.cout) out[(((size_t)n * p.cout + c) * p.OH + oy) * p.OW + ox] = apply_act(acc[ct][r], p.act);
             }
     } else {  // OUT_U8HWC: x*255 -> clip(0,255) -> truncating cast  (_autoencoders.py:576-580)
         uint8_t *out = (uint8_t *)p.out;
@@ -199,7 +206,7 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const Layer
             for (int r = 0; r < 16; ++r) {
                 const int c = 32 * ct + acc_row(r) + 4 * h;
                 if (c < p.cout) {
-                    float v = acc[ct][r] * 255.0f;
+                    float v = apply_act(acc[ct][r], p.act) * 255.0f;
                     v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
                     out[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + c] = (uint8_t)v;
                 }
@@ -216,11 +223,13 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const Layer
 #ifndef CAE_CONV_WAVES
 #define CAE_CONV_WAVES 2
 #endif
-template <int KS, int CT, int NW, bool GDN>
+// S = stride (2: DownsamplingUnit's strided conv; 1: the pre-activation conv of the LeakyReLU/ReLU units,
+// _autoencoders.py:62-70, and -- with ZEROPAD and flipped weights -- ConvTranspose2d(stride 1), :187-196)
+template <int KS, int CT, int NW, bool GDN, int S = 2, bool ZEROPAD = false>
 __global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : (CT <= 4 ? CAE_CONV_WAVES : 2)) conv_s2_kernel(const LayerArgs p) {
     constexpr int PAD = KS / 2;
     constexpr int TX = 16, TY = 2 * NW;
-    constexpr int WH = 2 * TX + KS - 2;  // halo columns
+    constexpr int WH = S * (TX - 1) + KS;  // halo columns
     constexpr int HALO_PIECES = TY * WH * 2;
     constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;
     constexpr int W_INSTR = KS * CT;
@@ -245,7 +254,7 @@ __global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : (CT <= 4 ? CAE
     // per-lane halo pieces: piece = (row r, column x, half) -> LDS offset 16*piece.  The byte offset
     // of every piece inside one 8-channel plane is fixed per kernel row ky (reflect padding resolved
     // here, once), so a stage's DMA is: scalar plane base + 32-bit lane offset.
-    unsigned hoff[MAXP][KS];
+    unsigned hoff[MAXP][KS];  // 0xFFFFFFFF: outside the image (zero padding)
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         int pc = (wave + i * NW) * 64 + lane;
@@ -253,10 +262,15 @@ __global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : (CT <= 4 ? CAE
         const int r = pc / (2 * WH);
         const int rem = pc - r * (2 * WH);
         const int x = rem >> 1;
-        const unsigned xo = (unsigned)reflect_idx(2 * ox0 - PAD + x, p.W) * 32u + (unsigned)(rem & 1) * 16u;
+        const int ixr = S * ox0 - PAD + x;
+        const bool xok = !ZEROPAD || (ixr >= 0 && ixr < p.W);
+        const unsigned xo = (unsigned)reflect_idx(ixr, p.W) * 32u + (unsigned)(rem & 1) * 16u;
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky)
-            hoff[i][ky] = (unsigned)reflect_idx(2 * (oy0 + r) - PAD + ky, p.H) * (unsigned)p.W * 32u + xo;
+        for (int ky = 0; ky < KS; ++ky) {
+            const int iyr = S * (oy0 + r) - PAD + ky;
+            const bool ok = xok && (!ZEROPAD || (iyr >= 0 && iyr < p.H));
+            hoff[i][ky] = ok ? (unsigned)reflect_idx(iyr, p.H) * (unsigned)p.W * 32u + xo : 0xFFFFFFFFu;
+        }
     }
     const size_t plane_bytes = (size_t)p.H * p.W * 32;
     const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
@@ -275,7 +289,13 @@ __global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : (CT <= 4 ? CAE
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             const int j = wave + i * NW;
-            if (j < HALO_INSTR) glds16(plane + hoff[i][ky], buf + W_BYTES + j * 1024);
+            if (j < HALO_INSTR) {
+                if (ZEROPAD)
+                    glds16(hoff[i][ky] != 0xFFFFFFFFu ? (const void *)(plane + hoff[i][ky]) : (const void *)p.zero,
+                           buf + W_BYTES + j * 1024);
+                else
+                    glds16(plane + hoff[i][ky], buf + W_BYTES + j * 1024);
+            }
         }
     };
 
@@ -283,7 +303,7 @@ __global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : (CT <= 4 ? CAE
     init_acc<CT>(acc, p.bias, h, 0.0f);
 
     const int wrow = 2 * wave + (m >> 4);
-    const int b_off = W_BYTES + ((wrow * WH + 2 * (m & 15)) * 8 + 4 * h) * 4;
+    const int b_off = W_BYTES + ((wrow * WH + S * (m & 15)) * 8 + 4 * h) * 4;
     int sc = 0;
 
     issue_stage(0, std::integral_constant<int, 0>{}, smem);

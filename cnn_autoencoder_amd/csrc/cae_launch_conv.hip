@@ -38,6 +38,43 @@ static int launch_conv_t(const LayerArgs &a, hipStream_t st) {
         default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct); \
     }
 
+// stride-1 convolutions of the LeakyReLU / ReLU units: reflect padded (analysis) or zero padded with
+// flipped weights (ConvTranspose2d stride 1, synthesis)
+template <int KS, int CT, bool ZP>
+static int launch_conv_s1_t(const LayerArgs &a, hipStream_t st) {
+    constexpr int NW = CAE_CONV_NW;
+    constexpr int WH = 15 + KS;
+    constexpr int HALO_INSTR = (2 * NW * WH * 2 + 63) / 64;
+    constexpr int LDS = 2 * (KS * CT * 1024 + HALO_INSTR * 1024);
+    auto kern = conv_s2_kernel<KS, CT, NW, false, 1, ZP>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int launch_conv_s1(int ks, int ct, bool zeropad, const LayerArgs &a, hipStream_t st) {
+#define S1_CT(KS_, ZP_)                                                          \
+    switch (ct) {                                                                \
+        case 1: return launch_conv_s1_t<KS_, 1, ZP_>(a, st);                     \
+        case 2: return launch_conv_s1_t<KS_, 2, ZP_>(a, st);                     \
+        case 4: return launch_conv_s1_t<KS_, 4, ZP_>(a, st);                     \
+        case 6: return launch_conv_s1_t<KS_, 6, ZP_>(a, st);                     \
+        default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct); \
+    }
+    if (ks == 3) {
+        if (zeropad) { S1_CT(3, true) } else { S1_CT(3, false) }
+    } else if (ks == 5) {
+        if (zeropad) { S1_CT(5, true) } else { S1_CT(5, false) }
+    }
+    return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+}
+
 int launch_conv(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
     if (ks == 3) {
         if (gdn) { DISPATCH_CT(launch_conv_t, 3, true) } else { DISPATCH_CT(launch_conv_t, 3, false) }

@@ -108,10 +108,25 @@ def initialize_weights(m):
             nn.init.constant_(m.bias.data, 0.01)
 
 
+_ACT_CODES = {None: 0, 'Identity': 0, 'GDN': 0, 'LeakyReLU': 1, 'ReLU': 2}
+
+
+def _define_act_layer(act_layer_type, channels_in=None, track='analysis'):
+    """reference _define_act_layer (_autoencoders.py:19-34)."""
+    if act_layer_type is None or act_layer_type == 'Identity':
+        return nn.Identity()
+    if act_layer_type == 'LeakyReLU':
+        return nn.LeakyReLU(inplace=False)
+    if act_layer_type == 'ReLU':
+        return nn.ReLU(inplace=False)
+    if act_layer_type == 'GDN':
+        return GDN(in_channels=channels_in, inverse=track == 'synthesis')
+    raise ValueError(f'Activation layer {act_layer_type} not supported')
+
+
 def _check_variant(kernel_size, groups, batch_norm, dropout, use_residual, act_layer_type, channels_expansion):
-    if act_layer_type not in (None, 'GDN'):
-        raise NotImplementedError(f"act_layer_type={act_layer_type!r}: only None and 'GDN' run on the HIP path "
-                                  '(LeakyReLU/ReLU units are a later scope row, SURVEY §8f.2)')
+    if act_layer_type not in (None, 'GDN', 'LeakyReLU', 'ReLU'):
+        raise ValueError(f'Activation layer {act_layer_type} not supported')
     if groups or batch_norm or use_residual or channels_expansion != 1:
         raise NotImplementedError('groups / batch_norm / use_residual / channels_expansion variants are not built yet')
     if kernel_size not in (3, 5):
@@ -119,24 +134,55 @@ def _check_variant(kernel_size, groups, batch_norm, dropout, use_residual, act_l
     del dropout  # Dropout2d is the identity in eval mode
 
 
-class DownsamplingUnit(nn.Module):
+class _Unit(nn.Module):
+    """model = [pre conv (stride 1) + act]? + strided (transposed) conv + [act | GDN]?  -- the module order,
+    hence the state-dict indices, of the reference's DownsamplingUnit / UpsamplingUnit."""
+
+    _conv_cls = StridedReflectConv2d
+    _track = 'analysis'
+
     def __init__(self, channels_in, channels_out, kernel_size=3, groups=False, batch_norm=False, dropout=0.0,
                  bias=False, act_layer_type=None):
         super().__init__()
-        model = [StridedReflectConv2d(channels_in, channels_out, kernel_size, bias)]
-        if act_layer_type == 'GDN':
-            model.append(GDN(channels_out, inverse=False))
+        model = []
+        self.pre_index = self.gdn_index = None
+        if act_layer_type is not None and act_layer_type not in ['GDN']:
+            self.pre_index = 0
+            model.append(self._conv_cls(channels_in, channels_in, kernel_size, bias))
+            model.append(_define_act_layer(act_layer_type, channels_in, track=self._track))
+        self.main_index = len(model)
+        model.append(self._conv_cls(channels_in, channels_out, kernel_size, bias))
+        if act_layer_type is not None:
+            if act_layer_type == 'GDN':
+                self.gdn_index = len(model)
+            model.append(_define_act_layer(act_layer_type, channels_out, track=self._track))
+        self.act_code = _ACT_CODES[act_layer_type]
         self.model = nn.Sequential(*model)
 
+    @property
+    def main(self):
+        return self.model[self.main_index]
 
-class UpsamplingUnit(nn.Module):
+    @property
+    def pre(self):
+        return None if self.pre_index is None else self.model[self.pre_index]
+
+    @property
+    def gdn(self):
+        return None if self.gdn_index is None else self.model[self.gdn_index]
+
+
+class DownsamplingUnit(_Unit):
+    pass
+
+
+class UpsamplingUnit(_Unit):
+    _conv_cls = StridedConvTranspose2d
+    _track = 'synthesis'
+
     def __init__(self, channels_in, channels_out, kernel_size=3, groups=False, batch_norm=False, dropout=0.0,
                  bias=True, act_layer_type=None):
-        super().__init__()
-        model = [StridedConvTranspose2d(channels_in, channels_out, kernel_size, bias)]
-        if act_layer_type == 'GDN':
-            model.append(GDN(channels_out, inverse=True))
-        self.model = nn.Sequential(*model)
+        super().__init__(channels_in, channels_out, kernel_size, groups, batch_norm, dropout, bias, act_layer_type)
 
 
 class _Track(nn.Module):
@@ -153,9 +199,8 @@ class _Track(nn.Module):
         import weakref
         ref = weakref.ref(self)
         for i, unit in enumerate(getattr(self, self._track_attr)):
-            for mod in unit.model:
-                if isinstance(mod, GDN):
-                    mod._owner = (ref, i)
+            if unit.gdn is not None:
+                unit.gdn._owner = (ref, i)
 
     def precision_code(self) -> int:
         """0 = exact fp32 MFMA, 1 = f16x3 split MFMA.  Attribute `precision` ('fp32' | 'f16x3'), else the
@@ -165,6 +210,8 @@ class _Track(nn.Module):
         prec = getattr(self, 'precision', None) or os.environ.get('CAE_PRECISION', 'f16x3')
         if prec not in ('fp32', 'f16x3'):
             raise ValueError(f"precision must be 'fp32' or 'f16x3', got {prec!r}")
+        if any(u.act_code for u in self._units()):
+            return 0  # LeakyReLU / ReLU units (stride-1 pre-convolutions) are built on the fp32 kernels
         return 1 if prec == 'f16x3' else 0
 
     def _units(self):
@@ -183,18 +230,27 @@ class _Track(nn.Module):
             L = _lib.lib()
             with torch.no_grad():
                 for i, unit in enumerate(self._units()):
-                    conv = unit.model[0]
+                    conv = unit.main
                     w = np.ascontiguousarray(conv.weight.detach().float().cpu().numpy())
                     b = None if conv.bias is None else np.ascontiguousarray(conv.bias.detach().float().cpu().numpy())
                     beta = gamma = None
-                    if len(unit.model) > 1:
-                        be, ga = unit.model[1].effective()
+                    if unit.gdn is not None:
+                        be, ga = unit.gdn.effective()
                         beta = np.ascontiguousarray(be.float().cpu().numpy())
                         gamma = np.ascontiguousarray(ga.float().cpu().numpy())
                     _lib.check(L.cae_model_set_layer(
                         self._handle.ptr, self._track_id, i, conv.in_channels, conv.out_channels,
                         w.ctypes.data, None if b is None else b.ctypes.data,
                         None if beta is None else beta.ctypes.data, None if gamma is None else gamma.ctypes.data))
+                    if unit.act_code or unit.pre is not None:
+                        pw = pb = None
+                        if unit.pre is not None:
+                            pw = np.ascontiguousarray(unit.pre.weight.detach().float().cpu().numpy())
+                            if unit.pre.bias is not None:
+                                pb = np.ascontiguousarray(unit.pre.bias.detach().float().cpu().numpy())
+                        _lib.check(L.cae_model_set_layer_act(
+                            self._handle.ptr, self._track_id, i, unit.act_code,
+                            None if pw is None else pw.ctypes.data, None if pb is None else pb.ctypes.data))
             self._versions = ver
         return self._handle
 

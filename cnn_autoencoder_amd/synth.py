@@ -98,16 +98,24 @@ def synthetic_state(cfg: Dict, seed: int = 0, stress: bool = False) -> Dict:
     def u(shape, b):
         return torch.from_numpy(rng.uniform(-b, b, shape).astype(np.float32))
 
+    act = cfg.get('act_layer_type')
+    pre = act in ('LeakyReLU', 'ReLU')  # units carry a stride-1 conv + activation in front (model.0, model.1)
     enc, dec = {}, {}
     cin = c_org
     for i in range(L):
         cout = c_net if i < L - 1 else c_bn
+        main = 0
+        if pre and i < L - 1:
+            enc[f'analysis_track.{i}.model.0.weight'] = u((cin, cin, k, k), _xavier_bound(cin, cin, k))
+            if bias:
+                enc[f'analysis_track.{i}.model.0.bias'] = u((cin,), 0.05)
+            main = 2
         w = u((cout, cin, k, k), _xavier_bound(cin, cout, k))
         if stress and i == L - 1:
             w = w * 40.0
-        enc[f'analysis_track.{i}.model.0.weight'] = w
+        enc[f'analysis_track.{i}.model.{main}.weight'] = w
         if bias:
-            enc[f'analysis_track.{i}.model.0.bias'] = torch.full((cout,), 0.01)
+            enc[f'analysis_track.{i}.model.{main}.bias'] = u((cout,), 0.05) if pre else torch.full((cout,), 0.01)
         if gdn and i < L - 1:
             beta = rng.uniform(0.5, 1.5, (cout,)).astype(np.float32)
             gamma = (0.1 * np.eye(cout) + rng.uniform(0, 0.02, (cout, cout))).astype(np.float32)
@@ -117,9 +125,15 @@ def synthetic_state(cfg: Dict, seed: int = 0, stress: bool = False) -> Dict:
     cin = c_bn
     for i in range(L):
         cout = c_net if i < L - 1 else c_org
-        dec[f'synthesis_track.{i}.model.0.weight'] = u((cin, cout, k, k), _xavier_bound(cin, cout, k))
+        main = 0
+        if pre and i < L - 1:
+            dec[f'synthesis_track.{i}.model.0.weight'] = u((cin, cin, k, k), _xavier_bound(cin, cin, k))
+            if bias:
+                dec[f'synthesis_track.{i}.model.0.bias'] = u((cin,), 0.05)
+            main = 2
+        dec[f'synthesis_track.{i}.model.{main}.weight'] = u((cin, cout, k, k), _xavier_bound(cin, cout, k))
         if bias:
-            dec[f'synthesis_track.{i}.model.0.bias'] = torch.full((cout,), 0.01)
+            dec[f'synthesis_track.{i}.model.{main}.bias'] = u((cout,), 0.05) if pre else torch.full((cout,), 0.01)
         if gdn and i < L - 1:
             beta = rng.uniform(0.5, 1.5, (cout,)).astype(np.float32)
             gamma = (0.1 * np.eye(cout) + rng.uniform(0, 0.02, (cout, cout))).astype(np.float32)

@@ -66,6 +66,15 @@ int cae_model_set_layer(cae_model_t *m, int track, int index, int cin, int cout,
                         const float *weight_host, const float *bias_host,
                         const float *beta_eff_host, const float *gamma_eff_host);
 
+/* LeakyReLU / ReLU variants of a unit (DownsamplingUnit _autoencoders.py:62-76,90-92; UpsamplingUnit
+ * :187-202,216-218): `act` (0 none, 1 LeakyReLU(0.01), 2 ReLU) is applied after the layer's strided
+ * (transposed) convolution; when pre_weight_host is given, a stride-1 convolution cin -> cin (analysis:
+ * weight (cin,cin,k,k), reflect padding; synthesis: ConvTranspose2d weight (cin,cin,k,k), padding k//2)
+ * plus the same activation runs in front of it.  Call after cae_model_set_layer for the same index.
+ * These variants run on the fp32 path. */
+int cae_model_set_layer_act(cae_model_t *m, int track, int index, int act, const float *pre_weight_host,
+                            const float *pre_bias_host);
+
 /* Arithmetic of the conv / GDN contraction: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32),
  * 1 = "f16x3": every operand split into two f16 halves, three f16 MFMAs per product, fp32
  * accumulate (22 significant bits; same 1e-4 parity bar, ~5x less matrix-pipe time).  Set before

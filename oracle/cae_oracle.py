@@ -92,32 +92,51 @@ def deconv_s2(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     return F.conv_transpose2d(x, w, bias, stride=2, padding=k // 2, output_padding=1)
 
 
-def analysis_forward(x: torch.Tensor, layers: Sequence[dict]) -> Tuple[torch.Tensor, List[torch.Tensor]]:
-    """GDN-variant Analyzer: layers[i] = {'weight', 'bias'?, 'beta'?, 'gamma'?}.
+def _act(fx: torch.Tensor, act: Optional[str]) -> torch.Tensor:
+    """_define_act_layer (_autoencoders.py:19-34): nn.LeakyReLU() (slope 0.01) / nn.ReLU()."""
+    if act == 'LeakyReLU':
+        return F.leaky_relu(fx, 0.01)
+    if act == 'ReLU':
+        return F.relu(fx)
+    return fx
 
-    Layer i = reflect conv s2 followed by GDN when 'beta' is present
-    (DownsamplingUnit with act_layer_type='GDN': model.0 = conv, model.1 = GDN;
-    last unit has act None, _autoencoders.py:343-351).
-    Returns (y, per-layer outputs).
+
+def analysis_forward(x: torch.Tensor, layers: Sequence[dict]) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """Analyzer: layers[i] = {'weight', 'bias'?, 'beta'?, 'gamma'?, 'pre_weight'?, 'pre_bias'?, 'act'?}.
+
+    GDN units (DownsamplingUnit with act_layer_type='GDN'): model.0 = conv s2, model.1 = GDN.
+    LeakyReLU / ReLU units (_autoencoders.py:62-92): model.0 = conv(cin,cin,s1,reflect), model.1 = act,
+    model.2 = conv s2, model.3 = act.  Last unit has act None (:343-351).  Returns (y, per-unit outputs).
     """
     outs = []
     fx = x
     for L in layers:
+        if L.get('pre_weight') is not None:
+            fx = _act(reflect_conv_s2(fx, L['pre_weight'], L.get('pre_bias'), stride=1), L.get('act'))
         fx = reflect_conv_s2(fx, L['weight'], L.get('bias'))
         if L.get('beta') is not None:
             fx = gdn_forward(fx, L['beta'], L['gamma'], inverse=False)
+        else:
+            fx = _act(fx, L.get('act'))
         outs.append(fx)
     return fx, outs
 
 
 def synthesis_forward(y: torch.Tensor, layers: Sequence[dict]) -> Tuple[torch.Tensor, List[torch.Tensor]]:
-    """GDN-variant Synthesizer (UpsamplingUnit: model.0 = convT, model.1 = IGDN)."""
+    """Synthesizer (UpsamplingUnit :177-227): GDN units model.0 = convT s2, model.1 = IGDN; LeakyReLU / ReLU
+    units model.0 = convT(cin,cin,s1,p=k//2), model.1 = act, model.2 = convT s2, model.3 = act."""
     outs = []
     fx = y
     for L in layers:
+        if L.get('pre_weight') is not None:
+            k = L['pre_weight'].shape[-1]
+            fx = _act(F.conv_transpose2d(fx, L['pre_weight'], L.get('pre_bias'), stride=1, padding=k // 2),
+                      L.get('act'))
         fx = deconv_s2(fx, L['weight'], L.get('bias'))
         if L.get('beta') is not None:
             fx = gdn_forward(fx, L['beta'], L['gamma'], inverse=True)
+        else:
+            fx = _act(fx, L.get('act'))
         outs.append(fx)
     return fx, outs
 

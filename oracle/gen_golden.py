@@ -163,6 +163,10 @@ def main():
     make_case(ref, 'gdn_mnist_32x32', mnist, synth.mnist_like(1)[0], 15, True, True)
     make_case(ref, 'gdn_k5bias_48x48', k5, synth.histo_tile(48, 3), 16, True, True)
     # canonical 128/192/L4 (weights rebuilt from the seed by synth.synthetic_state)
+    # LeakyReLU / ReLU units (stride-1 pre-convolutions; reference-pinned end to end, no GDN)
+    make_case(ref, 'lrelu_bias_small_40x56', dict(small, act_layer_type='LeakyReLU', bias=True), synth.histo_tile(40, 6, 56), 21, True, True)
+    make_case(ref, 'relu_small_37x45', dict(small, act_layer_type='ReLU'), rng.integers(0, 256, (37, 45, 3), dtype=np.uint8), 22, True, True)
+    make_case(ref, 'lrelu_k5_mid_48x48', dict(small, act_layer_type='LeakyReLU', kernel_size=5, channels_net=40, channels_bn=24), synth.histo_tile(48, 7), 23, False, False)
     make_case(ref, 'gdn_canonical_64x64', synth.CANONICAL, synth.histo_tile(64, 4), 17, False, False)
     make_case(ref, 'gdn_canonical_96x80', synth.CANONICAL, rng.integers(0, 256, (96, 80, 3), dtype=np.uint8), 18, False, False)
 

@@ -38,16 +38,23 @@ def golden_state(g, cfg):
 
 
 def oracle_layers(state, part):
-    """[{'weight','bias','beta','gamma'}] for oracle.analysis_forward / synthesis_forward."""
+    """[{'weight','bias','beta','gamma','pre_weight','pre_bias','act'}] for oracle.analysis_forward / synthesis_forward."""
     track = 'analysis_track' if part == 'encoder' else 'synthesis_track'
     sd = state[part]
+    act = state.get('act_layer_type')
+    act = act if act in ('LeakyReLU', 'ReLU') else None
     layers = []
     i = 0
     while f'{track}.{i}.model.0.weight' in sd:
-        layers.append(dict(weight=sd[f'{track}.{i}.model.0.weight'],
-                           bias=sd.get(f'{track}.{i}.model.0.bias'),
+        pre = f'{track}.{i}.model.2.weight' in sd  # [conv s1, act, conv s2, act]
+        m = 2 if pre else 0
+        layers.append(dict(weight=sd[f'{track}.{i}.model.{m}.weight'],
+                           bias=sd.get(f'{track}.{i}.model.{m}.bias'),
                            beta=sd.get(f'{track}.{i}.model.1.beta'),
-                           gamma=sd.get(f'{track}.{i}.model.1.gamma')))
+                           gamma=sd.get(f'{track}.{i}.model.1.gamma'),
+                           pre_weight=sd[f'{track}.{i}.model.0.weight'] if pre else None,
+                           pre_bias=sd.get(f'{track}.{i}.model.0.bias') if pre else None,
+                           act=act if pre else None))
         i += 1
     return layers
 

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 RTOL = ATOL = 1e-4
 
 CASES = ['noact_small_40x56', 'noact_small_37x45', 'gdn_small_40x56', 'gdn_small_37x45', 'gdn_mnist_32x32',
-         'gdn_k5bias_48x48', 'gdn_canonical_64x64', 'gdn_canonical_96x80']
+         'gdn_k5bias_48x48', 'gdn_canonical_64x64', 'gdn_canonical_96x80', 'lrelu_bias_small_40x56',
+         'relu_small_37x45', 'lrelu_k5_mid_48x48']
 
 
 @pytest.fixture(params=['fp32', 'f16x3'], autouse=True)

@@ -14,7 +14,8 @@ from oracle import c_oracle as C
 from oracle import cae_oracle as O
 
 CASES = ['noact_small_40x56', 'noact_small_37x45', 'gdn_small_40x56', 'gdn_small_37x45', 'gdn_mnist_32x32',
-         'gdn_k5bias_48x48', 'gdn_canonical_64x64', 'gdn_canonical_96x80']
+         'gdn_k5bias_48x48', 'gdn_canonical_64x64', 'gdn_canonical_96x80', 'lrelu_bias_small_40x56',
+         'relu_small_37x45', 'lrelu_k5_mid_48x48']
 
 
 @pytest.mark.parametrize('name', CASES)
