@@ -200,10 +200,17 @@ def test_init_and_state_dict_keys_match_reference_fixture(cae):
 
 
 def test_unsupported_variants_say_so(cae):
-    for kw in (dict(act_layer_type='LeakyReLU'), dict(use_residual=True), dict(batch_norm=True), dict(groups=True),
+    for kw in (dict(use_residual=True), dict(batch_norm=True), dict(groups=True),
                dict(channels_expansion=2), dict(kernel_size=7)):
         with pytest.raises(NotImplementedError):
             cae.Analyzer(3, 8, 16, 3, **kw)
+    with pytest.raises(ValueError, match='not supported'):  # the reference's own message (_autoencoders.py:32)
+        cae.Analyzer(3, 8, 16, 3, act_layer_type='LeakyRelU')
+    # LeakyReLU / ReLU units: reference module order -> state-dict indices model.0 (s1 conv) / model.2 (s2 conv)
+    a = cae.Analyzer(3, 8, 16, 3, act_layer_type='LeakyReLU', bias=True)
+    assert list(a.state_dict()) == [f'analysis_track.{i}.model.{j}.{p}' for i, js in ((0, (0, 2)), (1, (0, 2)), (2, (0,)))
+                                    for j in js for p in ('weight', 'bias')]
+    assert a.precision_code() == 0  # these variants run on the fp32 kernels
     with pytest.raises(NotImplementedError):
         cae.Synthesizer(3, 8, 16, 3, multiscale_analysis=True)
 
