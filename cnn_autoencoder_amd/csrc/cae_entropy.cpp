@@ -114,82 +114,136 @@ inline void classify(int32_t sym, int32_t offset, int32_t max_value, int32_t &va
     }
 }
 
-// symbols: (channels, hw) int32 in (c, y, x) raster order
-int encode_stream(const EntropyTables &T, const int32_t *symbols, int hw, uint8_t **out, size_t *out_len) {
-    // pass 1: exact upper bound on emitted words (one per coder step) + 2 flush words
+// ---- NS streams coded in lockstep by one thread ---------------------------------------------------
+// A range coder is one long dependency chain (state -> state); two independent streams walked
+// together let the out-of-order core overlap the two chains (~1.6x symbols per core-second).
+
+// exact number of coder steps of one stream (one 32-bit word can be emitted per step)
+static int count_steps(const EntropyTables &T, const int32_t *symbols, int hw, size_t *steps_out) {
     size_t steps = 0;
     for (int c = 0; c < T.channels; ++c) {
         const int32_t off = T.off[c], maxv = T.len[c] - 2;
         const int32_t *s = symbols + (size_t)c * hw;
-        for (int i = 0; i < hw; ++i) {
-            int32_t v;
-            uint32_t raw;
-            bool esc;
-            classify(s[i], off, maxv, v, raw, esc);
-            steps += 1;
-            // the escape code carries raw in 4-bit digits counted by a 32-bit shift loop upstream:
-            // values with raw >= 2^28 are not representable (upstream shifts by 32 there)
-            if (raw >= (1u << 28) || s[i] > (1 << 27) || s[i] < -(1 << 27))
-                return fail(CAE_ERR_ARG, "symbol %d (channel %d) is outside the codable range", s[i], c);
-            if (esc) {
+        size_t esc_steps = 0;
+        unsigned nesc = 0;  // branch-free (vectorisable) scan; escapes are rare
+        for (int i = 0; i < hw; ++i) nesc += (unsigned)(s[i] - off) >= (unsigned)maxv;
+        for (int i = 0; nesc && i < hw; ++i) {
+            const int32_t value = s[i] - off;
+            if (value < 0 || value >= maxv) {
+                int32_t v;
+                uint32_t raw;
+                bool esc;
+                classify(s[i], off, maxv, v, raw, esc);
+                // the escape code carries raw in 4-bit digits counted by a 32-bit shift loop upstream:
+                // values with raw >= 2^28 are not representable (upstream shifts by 32 there)
+                if (raw >= (1u << 28) || s[i] > (1 << 27) || s[i] < -(1 << 27))
+                    return fail(CAE_ERR_ARG, "symbol %d (channel %d) is outside the codable range", s[i], c);
                 const int nb = bypass_digits(raw);
-                steps += (size_t)(nb / (int)kMaxBypass) + 1 + nb;
+                esc_steps += (size_t)(nb / (int)kMaxBypass) + 1 + nb;
             }
         }
+        steps += (size_t)hw + esc_steps;
     }
-    const size_t cap = steps + 2;
-    uint32_t *buf = (uint32_t *)malloc(cap * sizeof(uint32_t));
-    if (!buf) return fail(CAE_ERR_NOMEM, "out of memory (%zu words)", cap);
-    BackWriter w{buf + cap};
-    uint64_t x = kRansL;
+    *steps_out = steps;
+    return CAE_OK;
+}
 
-    // pass 2: last symbol first; within a symbol the upstream stack order is
+// symbols[k]: (channels, hw) int32 in (c, y, x) raster order
+template <int NS>
+int encode_streams(const EntropyTables &T, const int32_t *const *symbols, int hw, uint8_t **out, size_t *out_len) {
+    uint32_t *buf[NS] = {};
+    size_t cap[NS];
+    BackWriter w[NS];
+    uint64_t x[NS];
+    for (int k = 0; k < NS; ++k) {
+        size_t steps;
+        int rc = count_steps(T, symbols[k], hw, &steps);
+        if (rc == CAE_OK) {
+            cap[k] = steps + 2;
+            buf[k] = (uint32_t *)malloc(cap[k] * sizeof(uint32_t));
+            if (!buf[k]) rc = fail(CAE_ERR_NOMEM, "out of memory (%zu words)", cap[k]);
+        }
+        if (rc != CAE_OK) {
+            for (int j = 0; j < k; ++j) free(buf[j]);
+            return rc;
+        }
+        w[k].ptr = buf[k] + cap[k];
+        x[k] = kRansL;
+    }
+    // last symbol first; within a symbol the upstream stack order is
     //   [main][prefix 15..][prefix rem][digit 0 .. digit n-1]  ->  popped in reverse
     for (int c = T.channels - 1; c >= 0; --c) {
         const int32_t off = T.off[c], maxv = T.len[c] - 2;
-        const int32_t *s = symbols + (size_t)c * hw;
         const EntropyTables::EncSym *es = T.enc.data() + (size_t)c * T.stride;
-        for (int i = hw - 1; i >= 0; --i) {
-            int32_t v;
-            uint32_t raw;
-            bool esc;
-            classify(s[i], off, maxv, v, raw, esc);
-            if (esc) {
+        const int32_t *s[NS];
+        for (int k = 0; k < NS; ++k) s[k] = symbols[k] + (size_t)c * hw;
+        auto step = [&](uint64_t &xs, uint32_t *&wp, int32_t sym) __attribute__((always_inline)) {
+            int32_t v = sym - off;
+            if (__builtin_expect((unsigned)v >= (unsigned)maxv, 0)) {
+                uint32_t raw;
+                bool esc;
+                BackWriter bw{wp};
+                classify(sym, off, maxv, v, raw, esc);
                 const int nb = bypass_digits(raw);
-                for (int j = nb - 1; j >= 0; --j) put_bits(x, w, (raw >> (j * kBypassBits)) & kMaxBypass);
-                put_bits(x, w, (uint32_t)(nb % (int)kMaxBypass));
-                for (int k = 0; k < nb / (int)kMaxBypass; ++k) put_bits(x, w, kMaxBypass);
+                for (int j = nb - 1; j >= 0; --j) put_bits(xs, bw, (raw >> (j * kBypassBits)) & kMaxBypass);
+                put_bits(xs, bw, (uint32_t)(nb % (int)kMaxBypass));
+                for (int q = 0; q < nb / (int)kMaxBypass; ++q) put_bits(xs, bw, kMaxBypass);
+                wp = bw.ptr;
             }
             const EntropyTables::EncSym &e = es[v];
             const uint64_t x_max = ((kRansL >> kPrecision) << 32) * (uint64_t)e.freq;
-            if (x >= x_max) {
-                w.put((uint32_t)x);
-                x >>= 32;
+            uint64_t xx = xs;
+            if (xx >= x_max) {
+                *--wp = (uint32_t)xx;
+                xx >>= 32;
             }
-            const uint64_t q = mul_hi(x, e.rcp_freq) >> e.rcp_shift;
-            x = x + e.bias + q * e.cmpl_freq;
+            const uint64_t q = mul_hi(xx, e.rcp_freq) >> e.rcp_shift;
+            xs = xx + e.bias + q * e.cmpl_freq;
+        };
+        if constexpr (NS == 2) {
+            uint64_t x0 = x[0], x1 = x[1];
+            uint32_t *p0 = w[0].ptr, *p1 = w[1].ptr;
+            const int32_t *s0 = s[0], *s1 = s[1];
+            for (int i = hw - 1; i >= 0; --i) {
+                step(x0, p0, s0[i]);
+                step(x1, p1, s1[i]);
+            }
+            x[0] = x0;
+            x[1] = x1;
+            w[0].ptr = p0;
+            w[1].ptr = p1;
+        } else {
+            uint64_t x0 = x[0];
+            uint32_t *p0 = w[0].ptr;
+            const int32_t *s0 = s[0];
+            for (int i = hw - 1; i >= 0; --i) step(x0, p0, s0[i]);
+            x[0] = x0;
+            w[0].ptr = p0;
         }
     }
-    w.put((uint32_t)(x >> 32));
-    w.put((uint32_t)x);
-    const size_t nbytes = (size_t)((buf + cap) - w.ptr) * sizeof(uint32_t);
-    uint8_t *res = (uint8_t *)malloc(nbytes ? nbytes : 1);
-    if (!res) {
-        free(buf);
-        return fail(CAE_ERR_NOMEM, "out of memory (%zu bytes)", nbytes);
+    int rc = CAE_OK;
+    for (int k = 0; k < NS; ++k) {
+        w[k].put((uint32_t)(x[k] >> 32));
+        w[k].put((uint32_t)x[k]);
+        const size_t nbytes = (size_t)((buf[k] + cap[k]) - w[k].ptr) * sizeof(uint32_t);
+        uint8_t *res = (uint8_t *)malloc(nbytes ? nbytes : 1);
+        if (!res) {
+            rc = fail(CAE_ERR_NOMEM, "out of memory (%zu bytes)", nbytes);
+        } else {
+            memcpy(res, w[k].ptr, nbytes);
+            out[k] = res;
+            out_len[k] = nbytes;
+        }
+        free(buf[k]);
     }
-    memcpy(res, w.ptr, nbytes);
-    free(buf);
-    *out = res;
-    *out_len = nbytes;
-    return CAE_OK;
+    return rc;
 }
 
 struct Reader {
     const uint8_t *p, *end;
     bool bad = false;
     inline uint32_t next() {
-        if (p + 4 > end) {
+        if (__builtin_expect(p + 4 > end, 0)) {
             bad = true;
             return 0;
         }
@@ -207,44 +261,59 @@ inline uint32_t get_bits(uint64_t &x, Reader &r) {
     return val;
 }
 
-int decode_stream(const EntropyTables &T, const uint8_t *buf, size_t len, int hw, int32_t *symbols) {
-    Reader r{buf, buf + len};
-    uint64_t x = r.next();
-    x |= (uint64_t)r.next() << 32;
-    if (r.bad) return fail(CAE_ERR_CORRUPT, "bitstream shorter than the 8-byte coder state");
+template <int NS>
+int decode_streams(const EntropyTables &T, const uint8_t *const *bufs, const size_t *lens, int hw,
+                   int32_t *const *symbols) {
+    Reader r[NS];
+    uint64_t x[NS];
+    for (int k = 0; k < NS; ++k) {
+        r[k] = Reader{bufs[k], bufs[k] + lens[k]};
+        x[k] = r[k].next();
+        x[k] |= (uint64_t)r[k].next() << 32;
+        if (r[k].bad) return fail(CAE_ERR_CORRUPT, "bitstream shorter than the 8-byte coder state");
+    }
     for (int c = 0; c < T.channels; ++c) {
         const int32_t *row = T.cdf.data() + (size_t)c * T.stride;
         const int32_t n = T.len[c], maxv = n - 2, off = T.off[c];
         const uint16_t *lutc = T.lut.data() + ((size_t)c << EntropyTables::kLutBits);
-        int32_t *s = symbols + (size_t)c * hw;
+        int32_t *s[NS];
+        for (int k = 0; k < NS; ++k) s[k] = symbols[k] + (size_t)c * hw;
         for (int i = 0; i < hw; ++i) {
-            const uint32_t cum = (uint32_t)(x & 0xFFFFu);
-            // largest v with row[v] <= cum: start at the bucket's first symbol, scan forward
-            int32_t v = lutc[cum >> (16 - EntropyTables::kLutBits)];
-            while (v < maxv && (uint32_t)row[v + 1] <= cum) ++v;
-            const uint32_t start = (uint32_t)row[v], freq = (uint32_t)(row[v + 1] - row[v]);
-            x = (uint64_t)freq * (x >> kPrecision) + (x & 0xFFFFu) - start;
-            if (x < kRansL) x = (x << 32) | r.next();
-            if (v == maxv) {
-                int32_t val = (int32_t)get_bits(x, r);
-                int32_t nb = val;
-                while (val == (int32_t)kMaxBypass && !r.bad) {
-                    val = (int32_t)get_bits(x, r);
-                    nb += val;
+#pragma GCC unroll 4
+            for (int k = 0; k < NS; ++k) {
+                uint64_t xx = x[k];
+                const uint32_t cum = (uint32_t)(xx & 0xFFFFu);
+                // largest v with row[v] <= cum: start at the bucket's first symbol, scan forward
+                int32_t v = lutc[cum >> (16 - EntropyTables::kLutBits)];
+                while (v < maxv && (uint32_t)row[v + 1] <= cum) ++v;
+                const uint32_t start = (uint32_t)row[v], freq = (uint32_t)(row[v + 1] - row[v]);
+                xx = (uint64_t)freq * (xx >> kPrecision) + (xx & 0xFFFFu) - start;
+                if (xx < kRansL) xx = (xx << 32) | r[k].next();
+                if (__builtin_expect(v == maxv, 0)) {
+                    int32_t val = (int32_t)get_bits(xx, r[k]);
+                    int32_t nb = val;
+                    while (val == (int32_t)kMaxBypass && !r[k].bad) {
+                        val = (int32_t)get_bits(xx, r[k]);
+                        nb += val;
+                    }
+                    int32_t raw = 0;
+                    for (int j = 0; j < nb && !r[k].bad; ++j) {
+                        val = (int32_t)get_bits(xx, r[k]);
+                        raw |= (int32_t)((uint32_t)val << (j * kBypassBits));
+                    }
+                    v = raw >> 1;
+                    if (raw & 1)
+                        v = -v - 1;
+                    else
+                        v += maxv;
                 }
-                int32_t raw = 0;
-                for (int j = 0; j < nb && !r.bad; ++j) {
-                    val = (int32_t)get_bits(x, r);
-                    raw |= (int32_t)((uint32_t)val << (j * kBypassBits));
-                }
-                v = raw >> 1;
-                if (raw & 1)
-                    v = -v - 1;
-                else
-                    v += maxv;
+                x[k] = xx;
+                s[k][i] = v + off;
             }
-            s[i] = v + off;
-            if (r.bad) return fail(CAE_ERR_CORRUPT, "bitstream ran past its end (channel %d, element %d)", c, i);
+            bool bad = false;
+            for (int k = 0; k < NS; ++k) bad |= r[k].bad;
+            if (__builtin_expect(bad, 0))
+                return fail(CAE_ERR_CORRUPT, "bitstream ran past its end (channel %d, element %d)", c, i);
         }
     }
     return CAE_OK;
@@ -345,8 +414,17 @@ int cae_rans_encode_batch(cae_model_t *mm, const int32_t *symbols, int n_streams
     }
     const EntropyTables &T = m->ent;
     const size_t per = (size_t)T.channels * hw;
-    int rc = parallel_streams(n_streams, threads,
-                              [&](int i) { return encode_stream(T, symbols + per * i, hw, &out_bufs[i], &out_lens[i]); });
+    // work item = two streams coded in lockstep (a lone last stream goes alone)
+    const int items = (n_streams + 1) / 2;
+    int rc = parallel_streams(items, threads, [&](int it) {
+        const int i = 2 * it;
+        if (i + 1 < n_streams) {
+            const int32_t *sy[2] = {symbols + per * i, symbols + per * (i + 1)};
+            return encode_streams<2>(T, sy, hw, &out_bufs[i], &out_lens[i]);
+        }
+        const int32_t *sy[1] = {symbols + per * i};
+        return encode_streams<1>(T, sy, hw, &out_bufs[i], &out_lens[i]);
+    });
     if (rc != 0)
         for (int i = 0; i < n_streams; ++i) {
             free(out_bufs[i]);
@@ -363,8 +441,16 @@ int cae_rans_decode_batch(cae_model_t *mm, const uint8_t *const *bufs, const siz
     if (n_streams < 1 || hw < 0) return fail(CAE_ERR_ARG, "bad shape");
     const EntropyTables &T = m->ent;
     const size_t per = (size_t)T.channels * hw;
-    return parallel_streams(n_streams, threads,
-                            [&](int i) { return decode_stream(T, bufs[i], lens[i], hw, symbols + per * i); });
+    const int items = (n_streams + 1) / 2;
+    return parallel_streams(items, threads, [&](int it) {
+        const int i = 2 * it;
+        if (i + 1 < n_streams) {
+            int32_t *sy[2] = {symbols + per * i, symbols + per * (i + 1)};
+            return decode_streams<2>(T, bufs + i, lens + i, hw, sy);
+        }
+        int32_t *sy[1] = {symbols + per * i};
+        return decode_streams<1>(T, bufs + i, lens + i, hw, sy);
+    });
 }
 
 }  // extern "C"
