@@ -22,6 +22,7 @@ _lib = None
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
 c_size_t = ctypes.c_size_t
+c_float = ctypes.c_float
 
 # every symbol include/cae_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -39,6 +40,8 @@ SYMBOLS = {
     'cae_gdn_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_quantize': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'cae_dequantize': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'cae_model_set_density': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float]),
+    'cae_likelihood': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cae_tile_sse': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
     'cae_model_set_profiling': (c_int, [c_void_p, c_int]),
     'cae_model_get_profile': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]),

@@ -252,6 +252,11 @@ int Model::ensure_device() {
         if (rc) return rc;
         medians_dirty = false;
     }
+    if (density_dirty && !density.empty()) {
+        int rc = upload(density, &density_dev);
+        if (rc) return rc;
+        density_dirty = false;
+    }
     return CAE_OK;
 }
 
@@ -275,6 +280,8 @@ Model::~Model() {
         if (ws16[i]) (void)hipFree(ws16[i]);
     if (zero) (void)hipFree(zero);
     if (medians_dev) (void)hipFree(medians_dev);
+    if (density_dev) (void)hipFree(density_dev);
+    if (bits_ws) (void)hipFree(bits_ws);
 }
 
 // ---- kernel dispatch ---------------------------------------------------------------------------
@@ -313,6 +320,13 @@ static unsigned ew_grid(size_t total) {
 }  // namespace cae
 
 using namespace cae;
+
+template <int R>
+static void launch_likelihood(Model *m, const float *y, int n, int hw, float *yhat, float *lik, double *part,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(likelihood_kernel<R>, dim3(m->c_bn, n), dim3(256), 0, st, y, m->medians_dev, m->density_dev,
+                       m->density_per_channel, m->density_k, m->density_bound, m->c_bn, hw, yhat, lik, part);
+}
 
 extern "C" {
 
@@ -868,6 +882,103 @@ int cae_quantize(cae_model_t *mm, const float *latents, int n, int hw, int32_t *
     hipLaunchKernelGGL(quantize_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, latents,
                        m->medians_dev, symbols, m->c_bn, hw, total);
     HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_model_set_density(cae_model_t *mm, int channels, int n_filters, const int *filters, const float *const *matrices,
+                          const float *const *biases, const float *const *factors, float likelihood_bound) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !filters || !matrices || !biases || !factors) return fail(CAE_ERR_ARG, "NULL argument");
+    if (channels != m->c_bn) return fail(CAE_ERR_ARG, "density model has %d channels, model %d", channels, m->c_bn);
+    if (n_filters < 1) return fail(CAE_ERR_UNSUPPORTED, "density network needs at least one hidden layer");
+    int R = 0;
+    for (int i = 0; i < n_filters; ++i) {
+        if (filters[i] < 1) return fail(CAE_ERR_ARG, "filters[%d]=%d", i, filters[i]);
+        R = std::max(R, filters[i]);
+    }
+    if (R > 8) return fail(CAE_ERR_UNSUPPORTED, "density filters wider than 8 are not supported (got %d)", R);
+    for (int i = 0; i <= n_filters; ++i)
+        if (!matrices[i] || !biases[i] || (i < n_filters && !factors[i])) return fail(CAE_ERR_ARG, "NULL parameter %d", i);
+    const int K = n_filters;
+    const int per = 3 * R + (K - 1) * (R * R + 2 * R) + R + 1;
+    std::vector<float> packed((size_t)channels * per, 0.f);
+    // narrower layers are embedded in width R with zero weights: the extra units stay exactly 0
+    auto width = [&](int i) { return i == 0 ? 1 : (i == K + 1 ? 1 : filters[i - 1]); };  // F[i]
+    for (int c = 0; c < channels; ++c) {
+        float *o = packed.data() + (size_t)c * per;
+        for (int i = 0; i <= K; ++i) {
+            const int fin = width(i), fout = width(i + 1);
+            const float *M = matrices[i] + (size_t)c * fout * fin;
+            const float *b = biases[i] + (size_t)c * fout;
+            const float *t = i < K ? factors[i] + (size_t)c * fout : nullptr;
+            if (i == 0) {
+                for (int j = 0; j < fout; ++j) { o[j] = M[j]; o[R + j] = b[j]; o[2 * R + j] = t[j]; }
+                o += 3 * R;
+            } else if (i < K) {
+                for (int j = 0; j < fout; ++j) {
+                    for (int k = 0; k < fin; ++k) o[j * R + k] = M[j * fin + k];
+                    o[R * R + j] = b[j];
+                    o[R * R + R + j] = t[j];
+                }
+                o += R * R + 2 * R;
+            } else {
+                for (int k = 0; k < fin; ++k) o[k] = M[k];
+                o[R] = b[0];
+            }
+        }
+    }
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->density.swap(packed);
+    m->density_r = R;
+    m->density_k = K;
+    m->density_per_channel = per;
+    m->density_bound = likelihood_bound > 0.f ? likelihood_bound : 0.f;
+    m->density_dirty = true;
+    return CAE_OK;
+}
+
+int cae_likelihood(cae_model_t *mm, const float *latents, int n, int hw, float *y_hat, float *likelihood, double *bits,
+                   void *stream) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !latents) return fail(CAE_ERR_ARG, "NULL argument");
+    if (!y_hat && !likelihood && !bits) return fail(CAE_ERR_ARG, "no output requested");
+    if (m->ent.channels == 0) return fail(CAE_ERR_ARG, "entropy model not set");
+    if (m->density.empty()) return fail(CAE_ERR_ARG, "density model not set");
+    if (n < 1 || hw < 1 || n > 65535) return fail(CAE_ERR_ARG, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(m->mu);
+    int rc = m->ensure_device();
+    if (rc) return rc;
+    double *part = nullptr;
+    if (bits) {
+        const size_t need = (size_t)n * m->c_bn;
+        if (m->bits_ws_elems < need) {
+            if (m->bits_ws) {
+                HIP_TRY(hipDeviceSynchronize());
+                (void)hipFree(m->bits_ws);
+                m->bits_ws = nullptr;
+                m->bits_ws_elems = 0;
+            }
+            HIP_TRY(hipMalloc((void **)&m->bits_ws, need * sizeof(double)));
+            m->bits_ws_elems = need;
+        }
+        part = m->bits_ws;
+    }
+    switch (m->density_r) {
+        case 1: launch_likelihood<1>(m, latents, n, hw, y_hat, likelihood, part, st); break;
+        case 2: launch_likelihood<2>(m, latents, n, hw, y_hat, likelihood, part, st); break;
+        case 3: launch_likelihood<3>(m, latents, n, hw, y_hat, likelihood, part, st); break;
+        case 4: launch_likelihood<4>(m, latents, n, hw, y_hat, likelihood, part, st); break;
+        case 5: launch_likelihood<5>(m, latents, n, hw, y_hat, likelihood, part, st); break;
+        case 6: launch_likelihood<6>(m, latents, n, hw, y_hat, likelihood, part, st); break;
+        case 7: launch_likelihood<7>(m, latents, n, hw, y_hat, likelihood, part, st); break;
+        default: launch_likelihood<8>(m, latents, n, hw, y_hat, likelihood, part, st); break;
+    }
+    HIP_TRY(hipGetLastError());
+    if (bits) {
+        hipLaunchKernelGGL(bits_reduce_kernel, dim3(n), dim3(256), 0, st, part, m->c_bn, bits);
+        HIP_TRY(hipGetLastError());
+    }
     return CAE_OK;
 }
 

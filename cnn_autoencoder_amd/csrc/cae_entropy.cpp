@@ -22,6 +22,8 @@
 #include <string>
 #include <thread>
 
+#include <sched.h>
+
 namespace cae {
 
 static constexpr uint64_t kRansL = 1ull << 31;
@@ -319,9 +321,26 @@ int decode_streams(const EntropyTables &T, const uint8_t *const *bufs, const siz
     return CAE_OK;
 }
 
+// Default size of the coder pool: CAE_CODER_THREADS, else the CPUs this process may run on, capped at 16
+// (one rank per GPU shares the host with the other ranks, and a container's CPU share is usually far below the
+// host's thread count; oversubscribing a 16-CPU share with 256 threads made small-tile batches 4x slower).
+int default_threads() {
+    static const int cached = [] {
+        if (const char *e = std::getenv("CAE_CODER_THREADS")) {
+            const int v = std::atoi(e);
+            if (v > 0) return v;
+        }
+        int ncpu = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) ncpu = std::min(ncpu > 0 ? ncpu : 1 << 20, CPU_COUNT(&set));
+        return std::max(1, std::min(ncpu, 16));
+    }();
+    return cached;
+}
+
 template <class F>
 int parallel_streams(int n, int threads, F f) {
-    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = default_threads();
     threads = std::max(1, std::min(threads, n));
     std::atomic<int> next{0};
     std::atomic<int> rc{0};

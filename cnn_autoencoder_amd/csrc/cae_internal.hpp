@@ -54,6 +54,14 @@ struct Model {
     EntropyTables ent;
     float *medians_dev = nullptr;
     bool medians_dirty = false;
+    // factorized density network (cae_model_set_density): effective parameters, uniform width
+    std::vector<float> density;
+    int density_r = 0, density_k = 0, density_per_channel = 0;
+    float density_bound = 0.f;
+    float *density_dev = nullptr;
+    bool density_dirty = false;
+    double *bits_ws = nullptr;
+    size_t bits_ws_elems = 0;
     float *zero = nullptr;
     void *ws[3] = {nullptr, nullptr, nullptr};
     size_t ws_bytes[3] = {0, 0, 0};

@@ -855,6 +855,93 @@ static __global__ void dequantize_kernel(const int32_t *sym, const float *median
     }
 }
 
+// ---- factorized density (EntropyBottleneck.__call__, eval mode) -------------------------
+// Per-channel density network of uniform hidden width R with K hidden layers, effective parameters
+// (softplus(matrix), bias, tanh(factor)) packed per channel as
+//   [M0 R][b0 R][t0 R]  { [Mi RxR][bi R][ti R] } i=1..K-1   [MK R][bK 1]
+template <int R>
+__device__ __forceinline__ float logits_cumulative(const float *__restrict__ p, int K, float x) {
+    float v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        v[j] = p[j] * x + p[R + j];
+        v[j] += p[2 * R + j] * tanhf(v[j]);
+    }
+    p += 3 * R;
+    for (int i = 1; i < K; ++i) {
+        float u[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < R; ++k) acc += p[j * R + k] * v[k];
+            acc += p[R * R + j];
+            u[j] = acc + p[R * R + R + j] * tanhf(acc);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = u[j];
+        p += R * R + 2 * R;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < R; ++k) acc += p[k] * v[k];
+    return acc + p[R];
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// One block per (channel, tile) plane: y_hat = round(y - m_c) + m_c, p = max(|sig(s*u) - sig(s*l)|, bound) with
+// l,u = logits(y_hat -/+ 0.5), s = -sign(l + u); bits_part[n][c] = -sum log2(p) over the plane (fixed order).
+template <int R>
+__global__ void __launch_bounds__(256)
+likelihood_kernel(const float *__restrict__ y, const float *__restrict__ medians, const float *__restrict__ params,
+                  int per_channel, int K, float bound, int C, int HW, float *__restrict__ yhat,
+                  float *__restrict__ lik, double *__restrict__ bits_part) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const float *pc = params + (size_t)c * per_channel;
+    const float med = medians[c];
+    const size_t base = ((size_t)n * C + c) * HW;
+    double bits = 0.0;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float q = rintf(y[base + i] - med) + med;
+        const float lo = logits_cumulative<R>(pc, K, q - 0.5f);
+        const float up = logits_cumulative<R>(pc, K, q + 0.5f);
+        const float t = lo + up;
+        const float sgn = t > 0.f ? -1.f : (t < 0.f ? 1.f : 0.f);
+        float pr = fabsf(sigmoidf(sgn * up) - sigmoidf(sgn * lo));
+        pr = fmaxf(pr, bound);
+        if (yhat) yhat[base + i] = q;
+        if (lik) lik[base + i] = pr;
+        bits -= (double)log2f(pr);
+    }
+    if (!bits_part) return;
+    __shared__ double red[256];
+    red[threadIdx.x] = bits;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bits_part[(size_t)n * C + c] = red[0];
+}
+
+// bits[n] = sum over channels of bits_part[n][c], fixed tree order (deterministic)
+static __global__ void bits_reduce_kernel(const double *part, int C, double *bits) {
+    __shared__ double red[256];
+    const int n = blockIdx.x;
+    double a = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) a += part[(size_t)n * C + c];
+    red[threadIdx.x] = a;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bits[n] = red[0];
+}
+
 // per-tile sum of squared byte differences; one block row per tile, exact integer partial sums
 static __global__ void tile_sse_kernel(const uint8_t *a, const uint8_t *b, size_t elems, unsigned long long *out) {
     const int tile = blockIdx.y;

@@ -112,6 +112,7 @@ class EntropyBottleneck(nn.Module):
 
         self._handle: Optional[_lib.Handle] = None
         self._tables_version = -1
+        self._density_version = None
 
     # ---- state dict: integer buffers change size with the model --------------------------------
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
@@ -141,6 +142,8 @@ class EntropyBottleneck(nn.Module):
     def forward(self, x: torch.Tensor, training: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         if training is None:
             training = self.training
+        if not training and x.is_cuda and not torch.is_grad_enabled():
+            return self._forward_hip(x)  # eval, no autograd: fused HIP kernel (cae_likelihood)
         perm = list(range(x.dim()))
         perm[0], perm[1] = 1, 0
         x = x.permute(*perm).contiguous()
@@ -157,6 +160,54 @@ class EntropyBottleneck(nn.Module):
         outputs = outputs.reshape(shape).permute(*perm).contiguous()
         likelihood = likelihood.reshape(shape).permute(*perm).contiguous()
         return outputs, likelihood
+
+    # ---- eval-mode density on the GPU (HIP kernel) -------------------------------------------------
+    def _sync_density(self) -> _lib.Handle:
+        """Upload softplus(_matrix), _bias, tanh(_factor) when they changed (cae_model_set_density)."""
+        if self._quantized_cdf.numel() == 0:
+            self.update()
+        h = self._sync_handle()
+        names = [n for n, _ in self.named_parameters(recurse=False) if n != 'quantiles']
+        ver = tuple((n, getattr(self, n)._version, getattr(self, n).data_ptr()) for n in names)
+        if self._density_version != ver:
+            k = len(self.filters)
+            params = self._params(cpu=True)
+            mats = [np.ascontiguousarray(F.softplus(params[f'_matrix{i:d}']).numpy(), dtype=np.float32) for i in range(k + 1)]
+            bias = [np.ascontiguousarray(params[f'_bias{i:d}'].numpy(), dtype=np.float32) for i in range(k + 1)]
+            fact = [np.ascontiguousarray(torch.tanh(params[f'_factor{i:d}']).numpy(), dtype=np.float32) for i in range(k)]
+            filt = (ctypes.c_int * max(k, 1))(*self.filters)
+            pm = (ctypes.c_void_p * (k + 1))(*[a.ctypes.data for a in mats])
+            pb = (ctypes.c_void_p * (k + 1))(*[a.ctypes.data for a in bias])
+            pf = (ctypes.c_void_p * (k + 1))(*([a.ctypes.data for a in fact] + [None]))
+            bound = float(self.likelihood_lower_bound.bound.item()) if self.use_likelihood_bound else 0.0
+            _lib.check(_lib.lib().cae_model_set_density(h.ptr, self.channels, k, filt, pm, pb, pf, bound))
+            self._density_version = ver
+        return h
+
+    def _likelihood_hip(self, x: torch.Tensor, want_outputs: bool, want_bits: bool):
+        dev = _lib.require_gpu()
+        if x.dim() < 3 or x.size(1) != self.channels:
+            raise ValueError(f'Invalid input shape {tuple(x.shape)} for {self.channels} channels')
+        h = self._sync_density()
+        x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        hw = int(np.prod(x.shape[2:]))
+        y_hat = torch.empty_like(x) if want_outputs else None
+        lik = torch.empty_like(x) if want_outputs else None
+        bits = torch.empty(x.size(0), dtype=torch.float64, device=dev) if want_bits else None
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        _lib.check(_lib.lib().cae_likelihood(h.ptr, x.data_ptr(), x.size(0), hw, ptr(y_hat), ptr(lik), ptr(bits),
+                                             _lib.stream_ptr()))
+        return y_hat, lik, bits
+
+    def _forward_hip(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        y_hat, lik, _ = self._likelihood_hip(x, True, False)
+        return y_hat, lik
+
+    @torch.no_grad()
+    def rate_bits(self, x: torch.Tensor) -> torch.Tensor:
+        """Estimated code length per batch item, -sum log2 p(y_hat) (float64, on the GPU): the numerator of
+        the reference's RateLoss (models/criteria/_ratedist.py:49-54) without materialising p."""
+        return self._likelihood_hip(x, False, True)[2]
 
     def loss(self) -> torch.Tensor:
         logits = _logits_cumulative(self._params(stop_gradient=True), len(self.filters), self.quantiles)

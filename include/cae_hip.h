@@ -114,6 +114,26 @@ int cae_gdn_forward(cae_model_t *m, int track, int index, const float *x_dev, in
 int cae_quantize(cae_model_t *m, const float *latents_dev, int n, int hw, int32_t *symbols_dev, void *stream);
 int cae_dequantize(cae_model_t *m, const int32_t *symbols_dev, int n, int hw, float *latents_dev, void *stream);
 
+/* Density network of the factorized prior (compressai EntropyBottleneck parameters `_matrix{i}`,
+ * `_bias{i}`, `_factor{i}`, i = 0..n_filters; the reference builds it at _autoencoders.py:476-477 with
+ * filters = [r]*K).  The caller passes EFFECTIVE values: matrices[i] = softplus(_matrix{i})
+ * (channels, F[i+1], F[i]), biases[i] (channels, F[i+1]), factors[i] = tanh(_factor{i})
+ * (channels, F[i+1]; i < n_filters), F = (1, filters..., 1).  likelihood_bound = 1e-9 in the
+ * reference (0 disables the lower bound).  Hidden widths up to 8. */
+int cae_model_set_density(cae_model_t *m, int channels, int n_filters, const int *filters,
+                          const float *const *matrices, const float *const *biases,
+                          const float *const *factors, float likelihood_bound);
+
+/* EntropyBottleneck.__call__ in eval mode (reference call site models/tasks/_taskutils.py:97 and
+ * the rate term -sum(log2 p) of models/criteria/_ratedist.py:49-54): for latents (n, channels, hw)
+ *   y_hat = round(y - median_c) + median_c,
+ *   likelihood = max(|sigmoid(s*u) - sigmoid(s*l)|, bound), l,u = logits_cumulative(y_hat -/+ 0.5),
+ *   bits[i] = -sum log2(likelihood) over tile i (float64, deterministic order).
+ * Any of y_hat_dev / likelihood_dev / bits_dev may be NULL.  Needs set_entropy (medians) and
+ * set_density.  Calls on one handle must be stream-ordered. */
+int cae_likelihood(cae_model_t *m, const float *latents_dev, int n, int hw, float *y_hat_dev,
+                   float *likelihood_dev, double *bits_dev, void *stream);
+
 /* Per-tile sum of squared differences of two (n, elems) uint8 batches -> sse_dev[n] (float64).
  * The distortion half of the per-tile statistics record the slide driver all-gathers (the
  * reference's harness computes MSE/PSNR on the host, test_cae.py:55-68). */
@@ -134,7 +154,7 @@ int cae_model_get_profile(cae_model_t *m, int track, double *ms, int n_slots, in
  * RansDecoder (encode_with_indexes / decode_with_indexes), reached from
  * EntropyBottleneck.update / compress / decompress (_autoencoders.py:502, :549-551, :568-571).
  * Streams are coded independently (one per tile), in parallel on `threads` host threads
- * (0 = hardware concurrency).  Symbol order inside a stream is (c, y, x) raster; the CDF row
+ * (0 = $CAE_CODER_THREADS, else min(CPUs of this process, 16)).  Symbol order inside a stream is (c, y, x) raster; the CDF row
  * of a symbol is its channel c. */
 int cae_pmf_to_quantized_cdf(const float *pmf_host, int n, int precision, uint32_t *cdf_host /* n+1 */);
 

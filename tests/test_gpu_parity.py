@@ -133,6 +133,54 @@ def test_quantize_and_bitstream_bit_exact(cae, fit, scale):
     assert torch.equal(o.decompress(strings, (7, 5), C.rans_decode_with_indexes), yq_ref)
 
 
+@pytest.mark.parametrize('filters,fit,scale', [((3, 3, 3, 3), True, 6.0), ((3, 3, 3, 3), False, 40.0),
+                                               ((5, 5), True, 6.0), ((2, 4, 3), True, 3.0), ((1,), False, 3.0)])
+def test_likelihood_matches_oracle(cae, filters, fit, scale):
+    """EntropyBottleneck.__call__ (eval): y_hat exact, likelihood within 1e-4 relative (fp32 transcendental
+    functions differ by ulps between torch-CPU and the device), rate estimate within 1e-5."""
+    from oracle import cae_oracle as O
+    torch.manual_seed(5)
+    eb = cae.EntropyBottleneck(20, filters=filters).eval()
+    with torch.no_grad():  # non-trivial factors and matrices (init has factor = 0)
+        for n, p in eb.named_parameters():
+            if n.startswith('_factor'):
+                p.uniform_(-1.0, 1.0)
+            elif n.startswith('_matrix'):
+                p.add_(torch.randn_like(p) * 0.3)
+    if fit:
+        eb.fit_quantiles()
+    eb.update(force=True)
+    o = O.EntropyBottleneckOracle(20, filters=filters)
+    o.load(eb.state_dict())
+    eb = eb.cuda()
+    y = torch.randn(3, 20, 9, 13) * scale
+    y_ref, p_ref = o.forward(y)
+    with torch.no_grad():
+        y_hat, p = eb(y.cuda())
+    assert torch.equal(y_hat.cpu(), y_ref)
+    # tolerance stated: 1e-4 relative on the likelihood, floor 1e-12 absolute (values are >= the 1e-9 bound)
+    np.testing.assert_allclose(p.cpu().numpy(), p_ref.numpy(), rtol=1e-4, atol=1e-12)
+    assert float(p.min()) >= 1e-9 * (1 - 1e-6)
+    bits = eb.rate_bits(y.cuda()).cpu().numpy()
+    bits_ref = -torch.log2(p_ref.double()).sum(dim=(1, 2, 3)).numpy()
+    np.testing.assert_allclose(bits, bits_ref, rtol=1e-5)
+    # the HIP path and the autograd (torch-op) path of the same module agree
+    y_t, p_t = eb(y.cuda().requires_grad_(True))
+    assert torch.equal(y_t.detach(), y_hat)
+    np.testing.assert_allclose(p_t.detach().cpu().numpy(), p.cpu().numpy(), rtol=1e-4, atol=1e-12)
+
+
+def test_rate_estimate_tracks_coded_size(cae):
+    """-sum log2 p (GPU) against the real rANS payload: the estimate is the coder's ideal length, so the coded
+    size must sit within a few percent above/below it on in-support latents."""
+    eb, _ = _eb_pair(cae, 48, True)
+    torch.manual_seed(7)
+    y = (torch.randn(4, 48, 32, 32) * 4.0).cuda()
+    bits = eb.rate_bits(y).cpu().numpy()
+    coded = np.array([8 * len(s) for s in eb.compress(y)], dtype=np.float64)
+    assert np.all(np.abs(coded - bits) / bits < 0.03)
+
+
 @pytest.mark.parametrize('name', ['gdn_small_40x56', 'gdn_canonical_64x64', 'gdn_mnist_32x32'])
 def test_codec_encode_decode(cae, name):
     """Codec byte format + end-to-end: header, payload = oracle coder on the GPU's latents,

@@ -272,6 +272,18 @@ def test_entropy_module_matches_oracle_on_cpu(cae):
     assert np.array_equal(eb.decode_symbols(strings, sym.shape[2]), sym)
 
 
+def test_density_upload_validates_filters(cae):
+    """cae_model_set_density (host side only): widths up to 8 are packed, wider ones refuse."""
+    eb = cae.EntropyBottleneck(6, filters=(2, 8, 3)).eval()
+    eb._sync_density()  # builds CDFs, packs the effective parameters; no device work
+    wide = cae.EntropyBottleneck(6, filters=(9,)).eval()
+    with pytest.raises(cae.CaeError, match='wider than 8'):
+        wide._sync_density()
+    if not torch.cuda.is_available():
+        with torch.no_grad(), pytest.raises(RuntimeError, match='no CPU fallback'):
+            eb.rate_bits(torch.zeros(1, 6, 2, 2))
+
+
 def test_entropy_state_dict_loads_integer_buffers(cae):
     torch.manual_seed(2)
     a = cae.EntropyBottleneck(6)
