@@ -660,7 +660,9 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
 
     // planes of the converted latents: padded so whole MFMA k-steps can be read (zero channels)
     const int p0 = f16 ? 4 * ((m->c_bn + 31) / 32) : (m->c_bn + 7) / 8;
-    size_t in_bytes = (size_t)n * p0 * lh * lw * 32;
+    // f16x3: the synthesis track keeps its activations in C8SP rows (pitch = whole 64-pixel blocks)
+    auto pitch = [&](int w) { return f16 ? (size_t)c8sp_pitch(w) : (size_t)w; };
+    size_t in_bytes = (size_t)n * p0 * lh * pitch(lw) * 32;
     size_t maxact = 0;
     {
         int ch = lh, cw = lw;
@@ -669,7 +671,7 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
                 maxact = std::max(maxact, (size_t)n * round_ct(m->dec[i].cin) * 4 * ch * cw * 32);
             ch *= 2;
             cw *= 2;
-            if (i + 1 < m->L) maxact = std::max(maxact, (size_t)n * m->dec[i].ct * 4 * ch * cw * 32);
+            if (i + 1 < m->L) maxact = std::max(maxact, (size_t)n * m->dec[i].ct * 4 * ch * pitch(cw) * 32);
         }
     }
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
@@ -680,7 +682,7 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
     const size_t tot = (size_t)n * p0 * lh * lw;
     if (f16)
         hipLaunchKernelGGL(nchw_to_c8s_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (char *)m->ws[0], n,
-                           m->c_bn, lh * lw, p0);
+                           m->c_bn, lh * lw, p0, lw);
     else
         hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (float *)m->ws[0], n,
                            m->c_bn, lh * lw, p0);
@@ -769,7 +771,7 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
             const size_t t2 = (size_t)n * l.cout * a.OH * a.OW;
             if (f16)
                 hipLaunchKernelGGL(c8s_to_nchw_kernel, dim3(ew_grid(t2)), dim3(256), 0, st, (const char *)a.out,
-                                   bridges[i], n, l.cout, a.OH * a.OW, l.ct * 4);
+                                   bridges[i], n, l.cout, a.OH * a.OW, l.ct * 4, a.OW);
             else
                 hipLaunchKernelGGL(c8_to_nchw_kernel, dim3(ew_grid(t2)), dim3(256), 0, st, (const float *)a.out,
                                    bridges[i], n, l.cout, a.OH * a.OW, l.ct * 4);

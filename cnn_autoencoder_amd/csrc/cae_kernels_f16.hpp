@@ -101,8 +101,18 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&yy)[PTA][CT], const Laye
             }
 }
 
-// store CT accumulator tiles of one pixel column-tile: C8S (split halves) | NCHW fp32 | HWC uint8
-template <int CT>
+// ---- C8SP: parity-split rows of the synthesis track --------------------------------------------------
+// A sub-pixel phase of the transposed convolution produces every second pixel of an output row.  Written into
+// plain C8S rows that is a 32-byte record every 64 bytes: half-written cache lines, measured at 1.3 of the
+// 3.7 ms of the largest layer (profiles/r01_experiments.md).  The synthesis track therefore keeps its rows
+// parity-split: inside every 64-pixel block the 32 even pixels come first, then the 32 odd ones, and the row
+// pitch is a whole number of blocks.  A phase then writes one contiguous 1-KiB run per wave instruction, and
+// the next layer's LDS-DMA reads alternate between two contiguous runs.
+__host__ __device__ __forceinline__ int c8sp_pos(int x) { return (x & ~63) | ((x & 1) << 5) | ((x & 63) >> 1); }
+__host__ __device__ __forceinline__ int c8sp_pitch(int w) { return (w + 63) & ~63; }  // records per row
+
+// store CT accumulator tiles of one pixel column-tile: C8S (split halves; SP: C8SP rows) | NCHW fp32 | HWC uint8
+template <int CT, bool SP = false>
 __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
                                                 int h, bool valid) {
     // (the half-wave exchange below needs both lanes of a pixel: lanes l and l+32 share (oy, ox),
@@ -132,7 +142,11 @@ __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const L
                 const auto r0 = __builtin_amdgcn_permlane32_swap(yh[0], xl[0], false, false);
                 const auto r1 = __builtin_amdgcn_permlane32_swap(yh[1], xl[1], false, false);
                 const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
-                char *dst = out + ((((size_t)n * p.out_planes + plane) * p.OH + oy) * p.OW + ox) * 32 + 16 * h;
+                const size_t row = ((size_t)n * p.out_planes + plane) * p.OH + oy;
+                char *dst = out + (SP ? row * c8sp_pitch(p.OW) + c8sp_pos(ox) : row * p.OW + ox) * 32 + 16 * h;
+#ifdef CAE_EXP_F16_NOSTORE  // timing-only ablation: activations are computed but not written (wrong results)
+                if (p.N < 0)
+#endif
                 *(u32x4 *)dst = v;
             }
     } else {
@@ -410,7 +424,7 @@ __device__ __forceinline__ void deconv_issue_f16(const LayerArgs &p, const char 
         if (j < G::HALO_INSTR) {
             const int iy = hrow[i] - d;
             const bool ok = iy >= 0 && iy < p.H && hbase[i] >= 0;
-            const char *src = ok ? planes + hbase[i] + (size_t)iy * p.W * 32 : (const char *)p.zero;
+            const char *src = ok ? planes + hbase[i] + (size_t)iy * c8sp_pitch(p.W) * 32 : (const char *)p.zero;
             glds16(src, buf + G::W_BYTES + j * 1024);
         }
     }
@@ -438,6 +452,7 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
         __syncthreads();
         char *cur = smem + (sc & 1) * STAGE_BYTES;
         char *nxt = smem + ((sc + 1) & 1) * STAGE_BYTES;
+#ifndef CAE_EXP_F16_NODMA  // timing-only ablation: no LDS-DMA after the first stage (wrong results)
         if (s + 1 < NS) {
             deconv_issue_f16<KS, CT, NW, PT, IGDN, PY>(p, in_n, plane_bytes, s + 1, nxt, hrow, hbase, wave, lane);
         } else if (IGDN) {
@@ -445,6 +460,7 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
         } else if (PY == 0) {
             deconv_issue_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, 0, nxt, hrow, hbase, wave, lane);
         }
+#endif
         const char *wb = cur + lane * 16;
         const char *hb = cur + b_off;
 #pragma unroll
@@ -460,8 +476,13 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const f16x8 ah = *(const f16x8 *)(wb + ((kx * CT + ct) * 2 + 0) * 1024);
-                const f16x8 al = *(const f16x8 *)(wb + ((kx * CT + ct) * 2 + 1) * 1024);
+#ifdef CAE_EXP_F16_FEWREADS  // timing-only ablation: one weight fragment pair per tap instead of CT (wrong results)
+                constexpr int ctr = 0;
+#else
+                const int ctr = ct;
+#endif
+                const f16x8 ah = *(const f16x8 *)(wb + ((kx * CT + ctr) * 2 + 0) * 1024);
+                const f16x8 al = *(const f16x8 *)(wb + ((kx * CT + ctr) * 2 + 1) * 1024);
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) {
                     if (px == 0)
@@ -477,7 +498,8 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
     auto store_px = [&](int x) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
-            store_tiles_f16<CT>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h, (iy + pt) < p.H && ix < p.W);
+            store_tiles_f16<CT, true>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h,
+                                      (iy + pt) < p.H && ix < p.W);
     };
     if constexpr (IGDN) {
         // one (px, row tile) at a time: 64 norm accumulators live instead of 128 (register budget);
@@ -492,7 +514,8 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
                     deconv_issue_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, 0, nxt, hrow, hbase, wave, lane);
                 }
             });
-            store_tiles_f16<CT>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h, (iy + pt) < p.H && ix < p.W);
+            store_tiles_f16<CT, true>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h,
+                                      (iy + pt) < p.H && ix < p.W);
         });
     } else {
         store_px(0);
@@ -502,7 +525,7 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
 
 // PT input rows per wave: PT = 2 halves the LDS bytes read per MFMA (4 fat waves, one block per CU)
 template <int KS, int CT, int NW, int PT, bool IGDN>
-__global__ void __launch_bounds__(NW * 64, 1) deconv_s2_f16_kernel(const LayerArgs p) {
+__global__ void __launch_bounds__(NW * 64, NW * PT <= 4 ? 2 : 1) deconv_s2_f16_kernel(const LayerArgs p) {
     using G = DeconvGeomF16<KS, CT, NW, PT, IGDN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -526,11 +549,11 @@ __global__ void __launch_bounds__(NW * 64, 1) deconv_s2_f16_kernel(const LayerAr
         const int r = rem / G::WH, x = rem - r * G::WH;
         const int ix = ix0 + x - G::DHI;
         hrow[i] = iy0 + r;
-        hbase[i] = (ix >= 0 && ix < p.W)
-                       ? (long)(plhl >> 1) * (long)((size_t)p.H * p.W * 32) + (long)ix * 32 + (plhl & 1) * 16
-                       : -1;
+        hbase[i] = (ix >= 0 && ix < p.W) ? (long)(plhl >> 1) * (long)((size_t)p.H * c8sp_pitch(p.W) * 32) +
+                                               (long)c8sp_pos(ix) * 32 + (plhl & 1) * 16
+                                         : -1;
     }
-    const size_t plane_bytes = (size_t)p.H * p.W * 32;
+    const size_t plane_bytes = (size_t)p.H * c8sp_pitch(p.W) * 32;  // input rows are C8SP
     const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
     // B operand: halo [pl = h][hl][row = PT*wave + pt][x = m + DHI - dx]
     const int b_off = G::W_BYTES + (((2 * h) * G::ROWS + PT * wave) * G::WH + m + G::DHI) * 16;
@@ -575,7 +598,7 @@ __global__ void __launch_bounds__(NW * 64, 2) deconv_last_f16_kernel(const Layer
     const int ty = bid % p.tiles_y;
     const int n = bid / p.tiles_y;
     const int iy0 = ty * NW, ix0 = tx * TXC;
-    const size_t plane_bytes = (size_t)p.H * p.W * 32;
+    const size_t plane_bytes = (size_t)p.H * c8sp_pitch(p.W) * 32;  // input rows are C8SP
     const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
 
     long hsrc[MAXP];
@@ -588,7 +611,9 @@ __global__ void __launch_bounds__(NW * 64, 2) deconv_last_f16_kernel(const Layer
         const int r = rem / WH, x = rem - r * WH;
         const int sy = iy0 - DHI + r, sx = ix0 - DHI + x;
         const bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
-        hsrc[i] = ok ? (long)(ghl >> 1) * (long)plane_bytes + ((long)sy * p.W + sx) * 32 + (ghl & 1) * 16 : -1;
+        hsrc[i] = ok ? (long)(ghl >> 1) * (long)plane_bytes + ((long)sy * c8sp_pitch(p.W) + c8sp_pos(sx)) * 32 +
+                           (ghl & 1) * 16
+                     : -1;
     }
     auto issue = [&](int q, char *buf) {
         const char *base = in_n + (size_t)(4 * q) * plane_bytes;
@@ -657,8 +682,8 @@ __global__ void __launch_bounds__(NW * 64, 2) deconv_last_f16_kernel(const Layer
     }
 }
 
-// fp32 NCHW -> C8S (module boundary / latents into the synthesis track)
-static __global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int HW, int planes) {
+// fp32 NCHW -> C8S (module boundary / latents into the synthesis track); W > 0: C8SP rows of width W
+static __global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int HW, int planes, int W = 0) {
     const size_t total = (size_t)N * planes * HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
@@ -675,20 +700,30 @@ static __global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int
             vh[k] = a;
             vl[k] = b;
         }
-        *(f16x8 *)(out + i * 32) = vh;
-        *(f16x8 *)(out + i * 32 + 16) = vl;
+        size_t rec = i;
+        if (W > 0) {
+            const int y = (int)(pix / W), x = (int)(pix % W);
+            rec = (np * (HW / W) + y) * c8sp_pitch(W) + c8sp_pos(x);
+        }
+        *(f16x8 *)(out + rec * 32) = vh;
+        *(f16x8 *)(out + rec * 32 + 16) = vl;
     }
 }
 
-// C8S -> fp32 NCHW (bridges)
-static __global__ void c8s_to_nchw_kernel(const char *in, float *out, int N, int C, int HW, int planes) {
+// C8S -> fp32 NCHW (bridges); W > 0: the source rows are C8SP of width W
+static __global__ void c8s_to_nchw_kernel(const char *in, float *out, int N, int C, int HW, int planes, int W = 0) {
     const size_t total = (size_t)N * C * HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
         const size_t nc = i / HW;
         const int c = (int)(nc % C);
         const size_t n = nc / C;
-        const _Float16 *rec = (const _Float16 *)(in + ((n * planes + (c >> 3)) * HW + pix) * 32);
+        size_t r = (n * planes + (c >> 3)) * HW + pix;
+        if (W > 0) {
+            const int y = (int)(pix / W), x = (int)(pix % W);
+            r = ((n * planes + (c >> 3)) * (HW / W) + y) * c8sp_pitch(W) + c8sp_pos(x);
+        }
+        const _Float16 *rec = (const _Float16 *)(in + r * 32);
         out[i] = (float)rec[c & 7] + (float)rec[8 + (c & 7)];
     }
 }

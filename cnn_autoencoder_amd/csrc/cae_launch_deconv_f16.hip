@@ -9,7 +9,10 @@ template <int KS, int CT, bool GDN>
 static int launch_deconv_f16_t(const LayerArgs &a, hipStream_t st) {
     // 8 waves x 1 input row measured faster than 4 waves x 2 rows (register spills at 512 VGPRs):
     // profiles/r01_experiments.md
-    constexpr int NW = 8, PT = 1;
+#ifndef CAE_DF16_NW
+#define CAE_DF16_NW 8
+#endif
+    constexpr int NW = CAE_DF16_NW, PT = 1;
     using G = DeconvGeomF16<KS, CT, NW, PT, GDN>;
     constexpr int LDS = 2 * G::STAGE_BYTES;
     if constexpr (LDS > 160 * 1024) {
@@ -21,8 +24,10 @@ static int launch_deconv_f16_t(const LayerArgs &a, hipStream_t st) {
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
             attr_done = true;
         }
-        const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a);
+        LayerArgs b = a;
+        b.tiles_y = (a.H + G::ROWS - 1) / G::ROWS;  // input rows per block follow the kernel's wave count
+        const unsigned grid = (unsigned)((size_t)b.N * b.tiles_x * b.tiles_y);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, b);
         HIP_TRY(hipGetLastError());
         return CAE_OK;
     }

@@ -12,8 +12,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--tile', type=int, default=1024)
 ap.add_argument('--iters', type=int, default=5)
+ap.add_argument('--act', default='GDN', help="'GDN' or 'none' (conv/deconv kernels without the fused normalisation)")
 args = ap.parse_args()
-cfg = dict(synth.CANONICAL)
+cfg = dict(synth.CANONICAL, act_layer_type=None if args.act == 'none' else args.act)
 model = cae.autoencoder_from_state_dict(synth.synthetic_state(cfg, seed=0))
 enc, dec = model['encoder'].module, model['decoder'].module
 tiles = torch.from_numpy(synth.uniform_tiles(args.batch, args.tile)).cuda()
