@@ -519,7 +519,9 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
     // workspace: ws[0] = converted input, ws[1]/ws[2] ping-pong.  fp32 C8 and split C8S records are
     // both 32 B per (plane, pixel), so the same buffers serve either precision.
     const int p0 = f16 ? 2 * ((m->c_org + 15) / 16) : (m->c_org + 7) / 8;
-    size_t in_bytes = first_fused ? 0 : (size_t)n * p0 * h * w * 32;
+    // f16x3: rows are padded to whole 32-pixel groups (C8S, cae_kernels_f16.hpp)
+    auto row_bytes = [&](int cw) { return f16 ? c8s_row_bytes<false>(cw) : (size_t)cw * 32; };
+    size_t in_bytes = first_fused ? 0 : (size_t)n * p0 * h * row_bytes(w);
     size_t maxact = 0;
     {
         int ch = h, cw = w;
@@ -528,9 +530,11 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
                 maxact = std::max(maxact, (size_t)n * round_ct(m->enc[i].cin) * 4 * ch * cw * 32);
             ch = (ch + 1) / 2;
             cw = (cw + 1) / 2;
-            if (i + 1 < m->L) maxact = std::max(maxact, (size_t)n * m->enc[i].ct * 4 * ch * cw * 32);
+            if (i + 1 < m->L) maxact = std::max(maxact, (size_t)n * m->enc[i].ct * 4 * ch * row_bytes(cw));
         }
     }
+    const bool u8_wide = f16 && !first_fused && fmt == CAE_FMT_U8_HWC;  // staged through fp32 C8 in ws[1]
+    if (u8_wide) maxact = std::max(maxact, (size_t)n * p0 * h * w * 32);
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
     if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
 
@@ -540,14 +544,14 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
         const size_t tot = (size_t)n * p0 * h * w;
         if (f16) {
             if (fmt == CAE_FMT_U8_HWC) {
-                // rare (more than 4 input channels): uint8 -> fp32 C8 (exact /255) -> split, in place
+                // rare (more than 4 input channels): uint8 -> fp32 C8 (exact /255) in ws[1] -> split rows in ws[0]
                 hipLaunchKernelGGL(u8hwc_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint8_t *)tiles,
-                                   (float *)m->ws[0], n, h, w, m->c_org, p0);
-                hipLaunchKernelGGL(c8_to_c8s_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)m->ws[0],
-                                   (char *)m->ws[0], tot);
+                                   (float *)m->ws[1], n, h, w, m->c_org, p0);
+                hipLaunchKernelGGL(c8_to_c8s_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)m->ws[1],
+                                   (char *)m->ws[0], (size_t)n * p0 * h, w);
             } else {
-                hipLaunchKernelGGL(nchw_to_c8s_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)tiles,
-                                   (char *)m->ws[0], n, m->c_org, h * w, p0);
+                hipLaunchKernelGGL(nchw_to_c8s_kernel<false>, dim3(ew_grid(tot)), dim3(256), 0, st,
+                                   (const float *)tiles, (char *)m->ws[0], n, m->c_org, h, w, p0);
             }
         } else if (fmt == CAE_FMT_U8_HWC) {
             hipLaunchKernelGGL(u8hwc_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint8_t *)tiles,
@@ -661,8 +665,8 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
     // planes of the converted latents: padded so whole MFMA k-steps can be read (zero channels)
     const int p0 = f16 ? 4 * ((m->c_bn + 31) / 32) : (m->c_bn + 7) / 8;
     // f16x3: the synthesis track keeps its activations in C8SP rows (pitch = whole 64-pixel blocks)
-    auto pitch = [&](int w) { return f16 ? (size_t)c8sp_pitch(w) : (size_t)w; };
-    size_t in_bytes = (size_t)n * p0 * lh * pitch(lw) * 32;
+    auto row_bytes = [&](int cw) { return f16 ? c8s_row_bytes<true>(cw) : (size_t)cw * 32; };
+    size_t in_bytes = (size_t)n * p0 * lh * row_bytes(lw);
     size_t maxact = 0;
     {
         int ch = lh, cw = lw;
@@ -671,7 +675,7 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
                 maxact = std::max(maxact, (size_t)n * round_ct(m->dec[i].cin) * 4 * ch * cw * 32);
             ch *= 2;
             cw *= 2;
-            if (i + 1 < m->L) maxact = std::max(maxact, (size_t)n * m->dec[i].ct * 4 * ch * pitch(cw) * 32);
+            if (i + 1 < m->L) maxact = std::max(maxact, (size_t)n * m->dec[i].ct * 4 * ch * row_bytes(cw));
         }
     }
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
@@ -681,8 +685,8 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
     prof.begin();
     const size_t tot = (size_t)n * p0 * lh * lw;
     if (f16)
-        hipLaunchKernelGGL(nchw_to_c8s_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (char *)m->ws[0], n,
-                           m->c_bn, lh * lw, p0, lw);
+        hipLaunchKernelGGL(nchw_to_c8s_kernel<true>, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (char *)m->ws[0], n,
+                           m->c_bn, lh, lw, p0);
     else
         hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (float *)m->ws[0], n,
                            m->c_bn, lh * lw, p0);
@@ -770,8 +774,8 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
         if (!last && bridges && bridges[i]) {
             const size_t t2 = (size_t)n * l.cout * a.OH * a.OW;
             if (f16)
-                hipLaunchKernelGGL(c8s_to_nchw_kernel, dim3(ew_grid(t2)), dim3(256), 0, st, (const char *)a.out,
-                                   bridges[i], n, l.cout, a.OH * a.OW, l.ct * 4, a.OW);
+                hipLaunchKernelGGL(c8s_to_nchw_kernel<true>, dim3(ew_grid(t2)), dim3(256), 0, st, (const char *)a.out,
+                                   bridges[i], n, l.cout, a.OH, a.OW, l.ct * 4);
             else
                 hipLaunchKernelGGL(c8_to_nchw_kernel, dim3(ew_grid(t2)), dim3(256), 0, st, (const float *)a.out,
                                    bridges[i], n, l.cout, a.OH * a.OW, l.ct * 4);

@@ -7,10 +7,12 @@
 // v_mfma_f32_32x32x2_f32: 5.3x less matrix-pipe time at fp32-class accuracy (measured through the
 // whole analysis stack: max |err| 1.5e-6 vs 1.1e-6 for plain fp32, both against fp64).
 //
-// HBM layout "C8S": activations are [N][P][H][W] records of 32 B = [8 x f16 hi][8 x f16 lo] for
-// the 8 channels of plane P.  Same bytes as fp32 C8, produced once in the epilogue of the
-// previous layer, so consumers never convert.  A 16-channel MFMA k-step = two planes; lane half h
-// of the wave supplies the 8 channels of plane 2q+h.
+// HBM layout "C8S": activations are [N][P][H][row], one 16-byte hi piece and one 16-byte lo piece
+// (8 x f16 each) per pixel for the 8 channels of plane P; a row is a sequence of 1-KiB groups
+// [32 hi pieces][32 lo pieces] (see "row layouts" below; C8SP is the synthesis track's variant).
+// Same bytes as fp32 C8, produced once in the epilogue of the previous layer, so consumers never
+// convert.  A 16-channel MFMA k-step = two planes; lane half h of the wave supplies the 8 channels
+// of plane 2q+h.
 //
 // Block = 4 waves, ONE block per CU (each wave may use the whole 512-entry register file):
 //   wave tile = all CT*32 output channels x 64 pixels (two 32-pixel MFMA column tiles), so every
@@ -101,15 +103,26 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&yy)[PTA][CT], const Laye
             }
 }
 
-// ---- C8SP: parity-split rows of the synthesis track --------------------------------------------------
-// A sub-pixel phase of the transposed convolution produces every second pixel of an output row.  Written into
-// plain C8S rows that is a 32-byte record every 64 bytes: half-written cache lines, measured at 1.3 of the
-// 3.7 ms of the largest layer (profiles/r01_experiments.md).  The synthesis track therefore keeps its rows
-// parity-split: inside every 64-pixel block the 32 even pixels come first, then the 32 odd ones, and the row
-// pitch is a whole number of blocks.  A phase then writes one contiguous 1-KiB run per wave instruction, and
-// the next layer's LDS-DMA reads alternate between two contiguous runs.
-__host__ __device__ __forceinline__ int c8sp_pos(int x) { return (x & ~63) | ((x & 1) << 5) | ((x & 63) >> 1); }
-__host__ __device__ __forceinline__ int c8sp_pitch(int w) { return (w + 63) & ~63; }  // records per row
+// ---- row layouts of the split format ------------------------------------------------------------------
+// A row of one 8-channel plane is a sequence of 1-KiB groups [32 hi pieces (16 B each)][32 lo pieces]:
+//   C8S  (analysis track):  group g holds pixels 32g .. 32g+31;
+//   C8SP (synthesis track): groups 2b and 2b+1 hold the even and the odd pixels of the 64-pixel block b.
+// Why: (1) an LDS-DMA instruction fetches the hi (or lo) pieces of consecutive pixels, which are now
+// contiguous 16-byte pieces (whole cache lines) instead of every second 16 bytes of interleaved records;
+// (2) a sub-pixel phase of the transposed convolution produces every second pixel of an output row; into
+// interleaved rows that was a 32-byte record every 64 bytes, i.e. half-written cache lines, measured at 1.3 of
+// the 3.7 ms of the largest layer (profiles/r01_experiments.md).  With parity-split rows a phase writes one
+// contiguous 1-KiB group per wave instruction.  The row pitch is a whole number of groups (blocks).
+template <bool SP>
+__host__ __device__ __forceinline__ size_t c8s_row_bytes(int w) {
+    return SP ? (size_t)((w + 63) >> 6) * 2048 : (size_t)((w + 31) >> 5) * 1024;
+}
+// byte offset of pixel x's hi piece inside its row; the lo piece is 512 bytes further
+template <bool SP>
+__host__ __device__ __forceinline__ unsigned c8s_piece(int x) {
+    return SP ? (unsigned)(x >> 6) * 2048u + (unsigned)(x & 1) * 1024u + (unsigned)((x & 63) >> 1) * 16u
+              : (unsigned)(x >> 5) * 1024u + (unsigned)(x & 31) * 16u;
+}
 
 // store CT accumulator tiles of one pixel column-tile: C8S (split halves; SP: C8SP rows) | NCHW fp32 | HWC uint8
 template <int CT, bool SP = false>
@@ -143,7 +156,7 @@ __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const L
                 const auto r1 = __builtin_amdgcn_permlane32_swap(yh[1], xl[1], false, false);
                 const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
                 const size_t row = ((size_t)n * p.out_planes + plane) * p.OH + oy;
-                char *dst = out + (SP ? row * c8sp_pitch(p.OW) + c8sp_pos(ox) : row * p.OW + ox) * 32 + 16 * h;
+                char *dst = out + row * c8s_row_bytes<SP>(p.OW) + c8s_piece<SP>(ox) + 512 * h;
 #ifdef CAE_EXP_F16_NOSTORE  // timing-only ablation: activations are computed but not written (wrong results)
                 if (p.N < 0)
 #endif
@@ -188,7 +201,7 @@ __global__ void __launch_bounds__(256, 1) conv_s2_f16_kernel(const LayerArgs p) 
     const int n = bid / p.tiles_y;
     const int oy0 = ty * TY, ox0 = tx * TX;
 
-    const size_t plane_bytes = (size_t)p.H * p.W * 32;
+    const size_t plane_bytes = (size_t)p.H * c8s_row_bytes<false>(p.W);
     const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
     unsigned hoff[MAXP][KS];
 #pragma unroll
@@ -198,11 +211,12 @@ __global__ void __launch_bounds__(256, 1) conv_s2_f16_kernel(const LayerArgs p) 
         const int plhl = pc / PLANE_PIECES;
         const int rem = pc - plhl * PLANE_PIECES;
         const int r = rem / WH, x = rem - r * WH;
-        const unsigned base = (unsigned)(plhl >> 1) * (unsigned)plane_bytes + (unsigned)(plhl & 1) * 16u +
-                              (unsigned)reflect_idx(2 * ox0 - PAD + x, p.W) * 32u;
+        const unsigned base = (unsigned)(plhl >> 1) * (unsigned)plane_bytes + (unsigned)(plhl & 1) * 512u +
+                              c8s_piece<false>(reflect_idx(2 * ox0 - PAD + x, p.W));
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
-            hoff[i][ky] = base + (unsigned)reflect_idx(2 * (oy0 + r) - PAD + ky, p.H) * (unsigned)p.W * 32u;
+            hoff[i][ky] = base + (unsigned)reflect_idx(2 * (oy0 + r) - PAD + ky, p.H) *
+                                     (unsigned)c8s_row_bytes<false>(p.W);
     }
     const unsigned woff = (unsigned)lane * 16u;
 
@@ -281,102 +295,210 @@ __global__ void __launch_bounds__(256, 1) conv_s2_f16_kernel(const LayerArgs p) 
     }
 }
 
+// GDN / IGDN with the whole packed gamma resident in LDS (no staging, no barriers): persistent kernels.
+template <int CT, bool INVERSE>
+__device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gbuf, const float *beta_lds, int lane) {
+    const int h = lane >> 5;
+    f32x16 nrm[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nrm[ct][r] = beta_lds[32 * ct + acc_row(r) + 4 * h];
+#pragma unroll
+    for (int jt = 0; jt < CT; ++jt) {
+        const char *gb = gbuf + jt * (CT * 4096) + lane * 16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            __builtin_amdgcn_sched_barrier(0);  // keep the y*y splits of later steps from being hoisted (registers)
+            f16x8 sh, sl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = y[jt][8 * s + e];
+                _Float16 a, b;
+                split_f16(v * v, a, b);
+                sh[e] = a;
+                sl[e] = b;
+            }
+#pragma unroll
+            for (int co = 0; co < CT; ++co) {
+                const f16x8 gh = *(const f16x8 *)(gb + ((co * 2 + s) * 2 + 0) * 1024);
+                const f16x8 gl = *(const f16x8 *)(gb + ((co * 2 + s) * 2 + 1) * 1024);
+                nrm[co] = mfma3(gh, gl, sh, sl, nrm[co]);
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float nv = nrm[ct][r];
+            y[ct][r] *= INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv);
+        }
+}
+
 // =================================================================================================
 // conv_first_f16_kernel: first analysis layer (Cin <= 4) on f16x3, input uint8 HWC or float NCHW.
 //   K = (tap, 4 channels): k-step s, lane half h covers taps 4s+2h, 4s+2h+1 (two float4 halo reads).
 //   packed weights: [s][ct][hl][lane][8]: W(cout, tap = 4s + 2(lane>>5) + (j>>2), ch = j&3)
-//   Output write (fp32-sized C8S records) bounds this layer: it is HBM-write limited.
+//   PERSISTENT: one block of 8 waves per CU walks over 16x16-pixel output tiles; the packed weights, the
+//   whole packed gamma, bias/beta and the /255 table stay in LDS, the next tile's input pixels are fetched
+//   into registers under the current tile's MFMAs.  (The one-tile-per-block form re-read 120 KB of weights
+//   and gamma per 128 output pixels and exposed its whole prologue: 1.9 ms, against 1.0 ms now.)
+//   The output write (fp32-sized split rows, 134 MB per 1024x1024 tile) bounds this layer.
 // =================================================================================================
 template <int KS, int CT, bool GDN>
-__global__ void __launch_bounds__(256, 2) conv_first_f16_kernel(const LayerArgs p, const FirstArgs f) {
-    constexpr int NW = 4;
-    constexpr int PAD = KS / 2;
-    constexpr int TX = 16, TY = 2 * NW;
-    constexpr int WH = 2 * TX + KS - 2, HH = 2 * TY + KS - 2;
-    constexpr int NS = (KS * KS + 3) / 4;  // k-steps of 4 taps
-    constexpr int W_BYTES = NS * CT * 2048;
-    constexpr int G_BYTES = GDN ? CT * 4096 : 0;
+struct FirstGeomF16 {
+    static constexpr int NW = 8;
+    static constexpr int PAD = KS / 2;
+    static constexpr int TX = 16, TY = 2 * NW;
+    static constexpr int WH = 2 * TX + KS - 2, HH = 2 * TY + KS - 2;
+    static constexpr int NS = (KS * KS + 3) / 4;  // k-steps of 4 taps
+    static constexpr int W_BYTES = NS * CT * 2048;
+    static constexpr int G_BYTES = GDN ? CT * CT * 4096 : 0;
+    static constexpr int HALO_BYTES = ((HH * WH * 16 + 1023) / 1024) * 1024;
+    static constexpr int VEC_BYTES = 1024 + ((2 * CT * 32 * 4 + 1023) / 1024) * 1024;  // /255 table | bias | beta
+    static constexpr int FIXED_BYTES = G_BYTES + W_BYTES + VEC_BYTES;
+    static constexpr int NBUF = FIXED_BYTES + 2 * HALO_BYTES <= 160 * 1024 ? 2 : 1;
+    static constexpr int LDS_BYTES = FIXED_BYTES + NBUF * HALO_BYTES;
+    static constexpr int NPOS = (HH * WH + NW * 64 - 1) / (NW * 64);  // halo pixels per thread
+};
+
+template <int KS, int CT, bool GDN, bool U8>
+__global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs p, const FirstArgs f) {
+    using G = FirstGeomF16<KS, CT, GDN>;
+    constexpr int NW = G::NW, PAD = G::PAD, TX = G::TX, TY = G::TY, WH = G::WH, HH = G::HH, NS = G::NS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *gbuf = smem;
-    char *wbuf = smem + 2 * G_BYTES;
-    char *hbuf = wbuf + W_BYTES;
-    float *lut = (float *)(hbuf + ((HH * WH * 16 + 1023) / 1024) * 1024);
+    char *wbuf = smem + G::G_BYTES;
+    float *lut = (float *)(wbuf + G::W_BYTES);
+    float *bias_lds = lut + 256;
+    float *beta_lds = bias_lds + CT * 32;
+    char *hbuf = smem + G::FIXED_BYTES;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, m = lane & 31;
-    int bid = blockIdx.x;
-    const int tx = bid % p.tiles_x;
-    bid /= p.tiles_x;
-    const int ty = bid % p.tiles_y;
-    const int n = bid / p.tiles_y;
-    const int oy0 = ty * TY, ox0 = tx * TX;
+    const int tiles_img = p.tiles_x * p.tiles_y;
+    const int total = p.N * tiles_img;
 
-    int sc = 0;
-    if (GDN) issue_gamma0<CT, NW>(p, gbuf, wave, lane);
-    for (int i = threadIdx.x; i < W_BYTES / 16; i += NW * 64)
-        *(f32x4 *)(wbuf + i * 16) = *(const f32x4 *)((const char *)p.wp + i * 16);
-    if (f.in_is_u8) {
-        for (int i = threadIdx.x; i < 256; i += NW * 64) lut[i] = (float)i / 255.0f;
-        __syncthreads();
+    // resident operands: gamma and weights by LDS-DMA (gbuf and wbuf are adjacent), small vectors by hand
+    for (int j = wave; j < (G::G_BYTES + G::W_BYTES) / 1024; j += NW) {
+        const char *src = j < G::G_BYTES / 1024 ? (const char *)p.gp + (size_t)j * 1024
+                                                 : (const char *)p.wp + (size_t)(j - G::G_BYTES / 1024) * 1024;
+        glds16(src + lane * 16, smem + j * 1024);
     }
-    for (int i = threadIdx.x; i < HH * WH; i += NW * 64) {
-        const int r = i / WH, x = i - r * WH;
-        const int iy = reflect_idx(2 * oy0 - PAD + r, p.H), ix = reflect_idx(2 * ox0 - PAD + x, p.W);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (f.in_is_u8) {
-            const uint8_t *src = (const uint8_t *)f.in + (((size_t)n * p.H + iy) * p.W + ix) * f.cin;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < f.cin) v[c] = lut[src[c]];
-        } else {
-            const float *src = (const float *)f.in + (size_t)n * f.cin * p.H * p.W + (size_t)iy * p.W + ix;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < f.cin) v[c] = src[(size_t)c * p.H * p.W];
-        }
-        *(f32x4 *)(hbuf + i * 16) = v;
+    for (int i = threadIdx.x; i < 256; i += NW * 64) lut[i] = (float)i / 255.0f;
+    for (int i = threadIdx.x; i < CT * 32; i += NW * 64) {
+        bias_lds[i] = p.bias ? p.bias[i] : 0.0f;
+        beta_lds[i] = (GDN && p.beta) ? p.beta[i] : 1.0f;
     }
-    __syncthreads();
 
-    f32x16 acc[1][CT];
-    init_acc<CT>(acc[0], p.bias, h, 0.0f);
-    const int wrow = 2 * wave + (m >> 4);
-    const char *hb = hbuf + ((2 * wrow) * WH + 2 * (m & 15)) * 16;
-    const char *wb = wbuf + lane * 16;
+    // next tile's input pixels, raw (4 bytes or 4 floats per pixel).  Branch-free on purpose: every load is
+    // issued unconditionally (clamped pixel / channel index) so that all of them stay in flight under the
+    // current tile's MFMAs; absent channels are zeroed when the values are committed to LDS.
+    // (the input format is a template parameter so that the loaded registers have a single definition: with a
+    //  run-time format the compiler joined the two load paths and waited for the data right after issuing)
+    typedef typename std::conditional<U8, uint8_t, float>::type raw_t;
+    raw_t raw[G::NPOS][4];
+    const int c_last = f.cin - 1;
+    auto fetch = [&](int t) {
+        const int n = t / tiles_img, rem = t - n * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        f16x8 bh, bl;
+        for (int k = 0; k < G::NPOS; ++k) {
+            int i = threadIdx.x + k * NW * 64;
+            i = i < HH * WH ? i : HH * WH - 1;
+            const int r = i / WH, x = i - r * WH;
+            const int iy = reflect_idx(2 * ty * TY - PAD + r, p.H), ix = reflect_idx(2 * tx * TX - PAD + x, p.W);
+            if constexpr (U8) {
+                const uint8_t *src = (const uint8_t *)f.in + (((size_t)n * p.H + iy) * p.W + ix) * f.cin;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            // tap index of this lane half: 4s + 2h + half  (compile-time per h)
-            const int t0 = 4 * s + half, t1 = 4 * s + 2 + half;
-            const int o0 = t0 < KS * KS ? ((t0 / KS) * WH + (t0 % KS)) * 16 : -1;
-            const int o1 = t1 < KS * KS ? ((t1 / KS) * WH + (t1 % KS)) * 16 : -1;
-            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-            if (o0 >= 0) v0 = *(const f32x4 *)(hb + o0);
-            if (o1 >= 0) v1 = *(const f32x4 *)(hb + o1);
+                for (int c = 0; c < 4; ++c) raw[k][c] = src[c < c_last ? c : c_last];
+            } else {
+                const float *src = (const float *)f.in + (size_t)n * f.cin * p.H * p.W + (size_t)iy * p.W + ix;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float v = h ? v1[c] : v0[c];
-                _Float16 a, b;
-                split_f16(v, a, b);
-                bh[4 * half + c] = a;
-                bl[4 * half + c] = b;
+                for (int c = 0; c < 4; ++c) raw[k][c] = src[(size_t)(c < c_last ? c : c_last) * p.H * p.W];
             }
         }
+    };
+    auto commit = [&](char *hb) {  // exact x/255 through the table
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const f16x8 ah = *(const f16x8 *)(wb + ((s * CT + ct) * 2 + 0) * 1024);
-            const f16x8 al = *(const f16x8 *)(wb + ((s * CT + ct) * 2 + 1) * 1024);
-            acc[0][ct] = mfma3(ah, al, bh, bl, acc[0][ct]);
+        for (int k = 0; k < G::NPOS; ++k) {
+            const int i = threadIdx.x + k * NW * 64;
+            if (i < HH * WH) {
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float val;
+                    if constexpr (U8) val = lut[raw[k][c]]; else val = raw[k][c];
+                    v[c] = c <= c_last ? val : 0.0f;
+                }
+                *(f32x4 *)(hb + i * 16) = v;
+            }
         }
+    };
+
+    int t = blockIdx.x;
+    if (t < total) fetch(t);
+    __syncthreads();  // table visible
+    if (t < total) commit(hbuf);
+    wait_vm0();
+    __syncthreads();
+
+    const int wrow = 2 * wave + (m >> 4);
+    const int hb_off = ((2 * wrow) * WH + 2 * (m & 15)) * 16;
+    const char *wb = wbuf + lane * 16;
+    int cur = 0;
+    for (; t < total; t += gridDim.x) {
+        const int tn = t + gridDim.x;
+        const bool has_next = tn < total;
+        if (has_next) fetch(tn);
+
+        const int n = t / tiles_img, rem = t - n * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const char *hb = hbuf + cur * G::HALO_BYTES + hb_off;
+        f32x16 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = bias_lds[32 * ct + acc_row(r) + 4 * h];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            f16x8 bh, bl;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                // tap index of this lane half: 4s + 2h + half  (compile-time per h)
+                const int t0 = 4 * s + half, t1 = 4 * s + 2 + half;
+                const int o0 = t0 < KS * KS ? ((t0 / KS) * WH + (t0 % KS)) * 16 : -1;
+                const int o1 = t1 < KS * KS ? ((t1 / KS) * WH + (t1 % KS)) * 16 : -1;
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+                if (o0 >= 0) v0 = *(const f32x4 *)(hb + o0);
+                if (o1 >= 0) v1 = *(const f32x4 *)(hb + o1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = h ? v1[c] : v0[c];
+                    _Float16 a, b;
+                    split_f16(v, a, b);
+                    bh[4 * half + c] = a;
+                    bl[4 * half + c] = b;
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const f16x8 ah = *(const f16x8 *)(wb + ((s * CT + ct) * 2 + 0) * 1024);
+                const f16x8 al = *(const f16x8 *)(wb + ((s * CT + ct) * 2 + 1) * 1024);
+                acc[ct] = mfma3(ah, al, bh, bl, acc[ct]);
+            }
+        }
+        if constexpr (GDN) gdn_resident_f16<CT, false>(acc, gbuf, beta_lds, lane);
+        const int oy = ty * TY + wrow, ox = tx * TX + (m & 15);
+        store_tiles_f16<CT>(acc, p, n, oy, ox, h, oy < p.OH && ox < p.OW);
+
+        if (G::NBUF == 1) __syncthreads();  // single halo buffer: everyone is done reading it
+        if (has_next) commit(hbuf + (G::NBUF == 2 ? (cur ^ 1) : 0) * G::HALO_BYTES);
+        __syncthreads();
+        cur ^= G::NBUF - 1;
     }
-    if constexpr (GDN) {
-        gdn_stages_f16<CT, 1, NW, false, G_BYTES>(acc, p, gbuf, sc, wave, lane, [](char *) {});
-    }
-    const int oy = oy0 + wrow, ox = ox0 + (m & 15);
-    store_tiles_f16<CT>(acc[0], p, n, oy, ox, h, oy < p.OH && ox < p.OW);
 }
 
 // =================================================================================================
@@ -424,7 +546,7 @@ __device__ __forceinline__ void deconv_issue_f16(const LayerArgs &p, const char 
         if (j < G::HALO_INSTR) {
             const int iy = hrow[i] - d;
             const bool ok = iy >= 0 && iy < p.H && hbase[i] >= 0;
-            const char *src = ok ? planes + hbase[i] + (size_t)iy * c8sp_pitch(p.W) * 32 : (const char *)p.zero;
+            const char *src = ok ? planes + hbase[i] + (size_t)iy * c8s_row_bytes<true>(p.W) : (const char *)p.zero;
             glds16(src, buf + G::W_BYTES + j * 1024);
         }
     }
@@ -549,11 +671,11 @@ __global__ void __launch_bounds__(NW * 64, NW * PT <= 4 ? 2 : 1) deconv_s2_f16_k
         const int r = rem / G::WH, x = rem - r * G::WH;
         const int ix = ix0 + x - G::DHI;
         hrow[i] = iy0 + r;
-        hbase[i] = (ix >= 0 && ix < p.W) ? (long)(plhl >> 1) * (long)((size_t)p.H * c8sp_pitch(p.W) * 32) +
-                                               (long)c8sp_pos(ix) * 32 + (plhl & 1) * 16
+        hbase[i] = (ix >= 0 && ix < p.W) ? (long)(plhl >> 1) * (long)((size_t)p.H * c8s_row_bytes<true>(p.W)) +
+                                               (long)c8s_piece<true>(ix) + (plhl & 1) * 512
                                          : -1;
     }
-    const size_t plane_bytes = (size_t)p.H * c8sp_pitch(p.W) * 32;  // input rows are C8SP
+    const size_t plane_bytes = (size_t)p.H * c8s_row_bytes<true>(p.W);  // input rows are C8SP
     const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
     // B operand: halo [pl = h][hl][row = PT*wave + pt][x = m + DHI - dx]
     const int b_off = G::W_BYTES + (((2 * h) * G::ROWS + PT * wave) * G::WH + m + G::DHI) * 16;
@@ -598,7 +720,7 @@ __global__ void __launch_bounds__(NW * 64, 2) deconv_last_f16_kernel(const Layer
     const int ty = bid % p.tiles_y;
     const int n = bid / p.tiles_y;
     const int iy0 = ty * NW, ix0 = tx * TXC;
-    const size_t plane_bytes = (size_t)p.H * c8sp_pitch(p.W) * 32;  // input rows are C8SP
+    const size_t plane_bytes = (size_t)p.H * c8s_row_bytes<true>(p.W);  // input rows are C8SP
     const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
 
     long hsrc[MAXP];
@@ -611,8 +733,8 @@ __global__ void __launch_bounds__(NW * 64, 2) deconv_last_f16_kernel(const Layer
         const int r = rem / WH, x = rem - r * WH;
         const int sy = iy0 - DHI + r, sx = ix0 - DHI + x;
         const bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
-        hsrc[i] = ok ? (long)(ghl >> 1) * (long)plane_bytes + ((long)sy * c8sp_pitch(p.W) + c8sp_pos(sx)) * 32 +
-                           (ghl & 1) * 16
+        hsrc[i] = ok ? (long)(ghl >> 1) * (long)plane_bytes + (long)sy * (long)c8s_row_bytes<true>(p.W) +
+                           (long)c8s_piece<true>(sx) + (ghl & 1) * 512
                      : -1;
     }
     auto issue = [&](int q, char *buf) {
@@ -682,9 +804,10 @@ __global__ void __launch_bounds__(NW * 64, 2) deconv_last_f16_kernel(const Layer
     }
 }
 
-// fp32 NCHW -> C8S (module boundary / latents into the synthesis track); W > 0: C8SP rows of width W
-static __global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int HW, int planes, int W = 0) {
-    const size_t total = (size_t)N * planes * HW;
+// fp32 NCHW -> split rows (module boundary / latents into the synthesis track); SP: C8SP rows, else C8S
+template <bool SP>
+__global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int H, int W, int planes) {
+    const size_t HW = (size_t)H * W, total = (size_t)N * planes * HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
         const size_t np = i / HW;
@@ -700,37 +823,30 @@ static __global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int
             vh[k] = a;
             vl[k] = b;
         }
-        size_t rec = i;
-        if (W > 0) {
-            const int y = (int)(pix / W), x = (int)(pix % W);
-            rec = (np * (HW / W) + y) * c8sp_pitch(W) + c8sp_pos(x);
-        }
-        *(f16x8 *)(out + rec * 32) = vh;
-        *(f16x8 *)(out + rec * 32 + 16) = vl;
+        char *dst = out + (np * H + pix / W) * c8s_row_bytes<SP>(W) + c8s_piece<SP>((int)(pix % W));
+        *(f16x8 *)dst = vh;
+        *(f16x8 *)(dst + 512) = vl;
     }
 }
 
-// C8S -> fp32 NCHW (bridges); W > 0: the source rows are C8SP of width W
-static __global__ void c8s_to_nchw_kernel(const char *in, float *out, int N, int C, int HW, int planes, int W = 0) {
-    const size_t total = (size_t)N * C * HW;
+// split rows -> fp32 NCHW (bridges)
+template <bool SP>
+__global__ void c8s_to_nchw_kernel(const char *in, float *out, int N, int C, int H, int W, int planes) {
+    const size_t HW = (size_t)H * W, total = (size_t)N * C * HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
         const size_t nc = i / HW;
         const int c = (int)(nc % C);
         const size_t n = nc / C;
-        size_t r = (n * planes + (c >> 3)) * HW + pix;
-        if (W > 0) {
-            const int y = (int)(pix / W), x = (int)(pix % W);
-            r = ((n * planes + (c >> 3)) * (HW / W) + y) * c8sp_pitch(W) + c8sp_pos(x);
-        }
-        const _Float16 *rec = (const _Float16 *)(in + r * 32);
-        out[i] = (float)rec[c & 7] + (float)rec[8 + (c & 7)];
+        const char *src = in + ((n * planes + (c >> 3)) * H + pix / W) * c8s_row_bytes<SP>(W) +
+                          c8s_piece<SP>((int)(pix % W));
+        out[i] = (float)((const _Float16 *)src)[c & 7] + (float)((const _Float16 *)(src + 512))[c & 7];
     }
 }
 
-// ---- layout conversions for the split format ------------------------------------------------------
-// fp32 C8 [..][8] -> C8S record [8 hi][8 lo]
-static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t npix) {
+// fp32 C8 [rows][W][8] -> C8S rows (more than 4 input channels given as uint8: rare)
+static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t rows, int W) {
+    const size_t npix = rows * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
         const f32x4 a = *(const f32x4 *)(in + i * 8), b = *(const f32x4 *)(in + i * 8 + 4);
         f16x8 vh, vl;
@@ -744,22 +860,9 @@ static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t npix)
             vh[4 + k] = x;
             vl[4 + k] = y;
         }
-        *(f16x8 *)(out + i * 32) = vh;
-        *(f16x8 *)(out + i * 32 + 16) = vl;
-    }
-}
-
-static __global__ void c8s_to_c8_kernel(const char *in, float *out, size_t npix) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
-        const f16x8 vh = *(const f16x8 *)(in + i * 32), vl = *(const f16x8 *)(in + i * 32 + 16);
-        f32x4 a, b;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            a[k] = (float)vh[k] + (float)vl[k];
-            b[k] = (float)vh[4 + k] + (float)vl[4 + k];
-        }
-        *(f32x4 *)(out + i * 8) = a;
-        *(f32x4 *)(out + i * 8 + 4) = b;
+        char *dst = out + (i / W) * c8s_row_bytes<false>(W) + c8s_piece<false>((int)(i % W));
+        *(f16x8 *)dst = vh;
+        *(f16x8 *)(dst + 512) = vl;
     }
 }
 

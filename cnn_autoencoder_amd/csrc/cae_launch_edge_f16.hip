@@ -1,5 +1,7 @@
 // (generated split of the launcher code: one translation unit per kernel family so hipcc
 //  compiles them in parallel; see cae_launch.hpp)
+#include <algorithm>
+
 #include "cae_hip.h"
 #include "cae_internal.hpp"
 #include "cae_launch.hpp"
@@ -7,20 +9,34 @@
 namespace cae {
 template <int KS, int CT, bool GDN>
 static int launch_first_f16_t(const LayerArgs &a, const FirstArgs &f, hipStream_t st) {
-    constexpr int NW = 4;
-    constexpr int WH = 2 * 16 + KS - 2, HH = 4 * NW + KS - 2;
-    constexpr int NS = (KS * KS + 3) / 4;
-    constexpr int LDS = 2 * (GDN ? CT * 4096 : 0) + NS * CT * 2048 + ((HH * WH * 16 + 1023) / 1024) * 1024 + 1024;
-    auto kern = conv_first_f16_kernel<KS, CT, GDN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
+    using G = FirstGeomF16<KS, CT, GDN>;
+    constexpr int LDS = G::LDS_BYTES;
+    if constexpr (LDS > 160 * 1024) {
+        return fail(CAE_ERR_UNSUPPORTED, "f16x3: first-layer operands exceed the LDS for this shape; use fp32");
+    } else {
+        auto kern_u8 = conv_first_f16_kernel<KS, CT, GDN, true>;
+        auto kern_f32 = conv_first_f16_kernel<KS, CT, GDN, false>;
+        static bool attr_done = false;
+        static int n_cu = 0;
+        if (!attr_done) {
+            HIP_TRY(hipFuncSetAttribute((const void *)kern_u8, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            HIP_TRY(hipFuncSetAttribute((const void *)kern_f32, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            int dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+            attr_done = true;
+        }
+        LayerArgs b = a;
+        b.tiles_x = (a.OW + G::TX - 1) / G::TX;
+        b.tiles_y = (a.OH + G::TY - 1) / G::TY;
+        const size_t total = (size_t)b.N * b.tiles_x * b.tiles_y;
+        if (total > 0x7fffffff) return fail(CAE_ERR_ARG, "batch too large");
+        // persistent: one block per CU walks over the tiles
+        const unsigned grid = (unsigned)std::min<size_t>(total, (size_t)std::max(n_cu, 1));
+        hipLaunchKernelGGL(f.in_is_u8 ? kern_u8 : kern_f32, dim3(grid), dim3(G::NW * 64), LDS, st, b, f);
+        HIP_TRY(hipGetLastError());
+        return CAE_OK;
     }
-    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, a, f);
-    HIP_TRY(hipGetLastError());
-    return CAE_OK;
 }
 
 int launch_first_f16(int ks, int ct, bool gdn, const LayerArgs &a, const FirstArgs &f, hipStream_t st) {
