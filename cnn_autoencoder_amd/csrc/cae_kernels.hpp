@@ -171,9 +171,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // ---- epilogue store of CT accumulator tiles ---------------------------------------------------
 // (oy, ox): this lane's output pixel; valid: inside the image.
-template <int CT>
-__device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
-                                            int h, bool valid) {
+// ACT = false compiles the activation out: with the run-time selector inside the element loops the last analysis
+// layer (NCHW epilogue, no activation) ran 3x slower (0.65 vs 0.21 ms), so callers branch once per tile instead.
+template <int CT, bool ACT>
+__device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
+                                                 int h, bool valid) {
     if (!valid) return;
     if (p.outfmt == OUT_C8) {
         float *out = (float *)p.out;
@@ -183,8 +185,9 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const Layer
             for (int g = 0; g < 4; ++g) {
                 const int plane = 4 * ct + g;
                 if (plane < p.out_planes) {
-                    f32x4 v = {apply_act(acc[ct][4 * g], p.act), apply_act(acc[ct][4 * g + 1], p.act),
-                               apply_act(acc[ct][4 * g + 2], p.act), apply_act(acc[ct][4 * g + 3], p.act)};
+                    f32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = ACT ? apply_act(acc[ct][4 * g + k], p.act) : acc[ct][4 * g + k];
                     float *dst = out + ((((size_t)n * p.out_planes + plane) * p.OH + oy) * p.OW + ox) * 8 + 4 * h;
                     *(f32x4 *)dst = v;
                 }
@@ -196,7 +199,8 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const Layer
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = 32 * ct + acc_row(r) + 4 * h;
-                if (c < p.cout) out[(((size_t)n * p.cout + c) * p.OH + oy) * p.OW + ox] = apply_act(acc[ct][r], p.act);
+                if (c < p.cout)
+                    out[(((size_t)n * p.cout + c) * p.OH + oy) * p.OW + ox] = ACT ? apply_act(acc[ct][r], p.act) : acc[ct][r];
             }
     } else {  // OUT_U8HWC: x*255 -> clip(0,255) -> truncating cast  (_autoencoders.py:576-580)
         uint8_t *out = (uint8_t *)p.out;
@@ -206,12 +210,21 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const Layer
             for (int r = 0; r < 16; ++r) {
                 const int c = 32 * ct + acc_row(r) + 4 * h;
                 if (c < p.cout) {
-                    float v = apply_act(acc[ct][r], p.act) * 255.0f;
+                    float v = (ACT ? apply_act(acc[ct][r], p.act) : acc[ct][r]) * 255.0f;
                     v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
                     out[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + c] = (uint8_t)v;
                 }
             }
     }
+}
+
+template <int CT, bool MAY_ACT = true>
+__device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
+                                            int h, bool valid) {
+    if (MAY_ACT && p.act != 0)
+        store_tiles_impl<CT, true>(acc, p, n, oy, ox, h, valid);
+    else
+        store_tiles_impl<CT, false>(acc, p, n, oy, ox, h, valid);
 }
 
 // =================================================================================================

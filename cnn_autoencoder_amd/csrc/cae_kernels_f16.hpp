@@ -163,7 +163,7 @@ __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const L
                 *(u32x4 *)dst = v;
             }
     } else {
-        store_tiles<CT>(acc, p, n, oy, ox, h, valid);
+        store_tiles<CT, false>(acc, p, n, oy, ox, h, valid);  // the f16x3 path has no activation variants
     }
 }
 
