@@ -689,119 +689,143 @@ __global__ void __launch_bounds__(NW * 64, NW * PT <= 4 ? 2 : 1) deconv_s2_f16_k
 }
 
 // =================================================================================================
-// deconv_last_f16_kernel: last synthesis layer (Cout <= 4, no IGDN) on v_mfma_f32_16x16x32_f16, C8S in.
+// deconv_last_f16_kernel: last synthesis layer (Cout <= 4, no IGDN) on v_mfma_f32_16x16x32_f16, C8SP in.
 //   D rows = 4c + p (p = 2 py + px), cols = 16 input pixels; K = (neighbour, cin); one MFMA k-step
 //   = 32 channels = 4 planes (lane group g = lane>>4 supplies plane 4q+g).
 //   packed weights: [nd][ndx][q][hl][lane][8]: A(row = lane&15, cin = 32q + 8(lane>>4) + j)
-//   LDS: halo chunk [g][hl][row][x] of 16-byte pieces, double-buffered; all weights resident.
+//   PERSISTENT: the layer is a 134 MB-per-tile read with ~1 FLOP per byte, i.e. bound by how many bytes are
+//   in flight.  One block per CU walks over (NW rows x 32 columns) input tiles with all weights resident and
+//   a DEPTH-deep ring of halo stages [g][hl][row][x] (16-byte pieces) filled by LDS-DMA, so that DEPTH-1
+//   stages (~40 KiB each) are always outstanding per CU; `s_waitcnt vmcnt(MAXP*(DEPTH-2))` retires exactly
+//   the oldest stage (every wave issues MAXP pieces per stage; stores issued in between only make the wait
+//   conservative).
 // =================================================================================================
-template <int KS, int NW>
-__global__ void __launch_bounds__(NW * 64, 2) deconv_last_f16_kernel(const LayerArgs p) {
-    constexpr int P = KS / 2;
-    constexpr int DLO = -((P + 1) / 2), DHI = (KS - 1 - P) / 2;
-    constexpr int NB = DHI - DLO + 1;
-    constexpr int TXC = 32, NT = TXC / 16;
-    constexpr int WH = TXC + NB - 1, HR = NW + NB - 1;
-    constexpr int PLANE_PIECES = HR * WH;
-    constexpr int HALO_PIECES = 8 * PLANE_PIECES;  // [g(4)][hl(2)]
-    constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;
-    constexpr int STAGE_BYTES = HALO_INSTR * 1024;
-    constexpr int MAXP = (HALO_INSTR + NW - 1) / NW;
+template <int KS, int NW_, int DEPTH_>
+struct LastGeomF16 {
+    static constexpr int NW = NW_, DEPTH = DEPTH_;
+    static constexpr int P = KS / 2;
+    static constexpr int DLO = -((P + 1) / 2), DHI = (KS - 1 - P) / 2;
+    static constexpr int NB = DHI - DLO + 1;
+    static constexpr int TXC = 32, NT = TXC / 16;
+    static constexpr int WH = TXC + NB - 1, HR = NW + NB - 1;
+    static constexpr int PLANE_PIECES = HR * WH;
+    static constexpr int HALO_PIECES = 8 * PLANE_PIECES;  // [g(4)][hl(2)]
+    static constexpr int MAXP = ((HALO_PIECES + 63) / 64 + NW - 1) / NW;  // LDS-DMA instructions per wave and stage
+    static constexpr int STAGE_BYTES = MAXP * NW * 1024;
+    static constexpr int lds_bytes(int nq) { return DEPTH * STAGE_BYTES + NB * NB * nq * 2048; }
+};
+
+template <int KS, int NW, int DEPTH>
+__global__ void __launch_bounds__(NW * 64, 1) deconv_last_f16_kernel(const LayerArgs p) {
+    using G = LastGeomF16<KS, NW, DEPTH>;
+    constexpr int DLO = G::DLO, DHI = G::DHI, NB = G::NB, NT = G::NT, WH = G::WH, HR = G::HR;
+    constexpr int PLANE_PIECES = G::PLANE_PIECES, MAXP = G::MAXP, STAGE_BYTES = G::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, col = lane & 15;
     const int nq = p.cci;  // 32-channel groups
-    char *wbuf = smem + 2 * STAGE_BYTES;
+    char *wbuf = smem + DEPTH * STAGE_BYTES;
 
-    int bid = blockIdx.x;
-    const int tx = bid % p.tiles_x;
-    bid /= p.tiles_x;
-    const int ty = bid % p.tiles_y;
-    const int n = bid / p.tiles_y;
-    const int iy0 = ty * NW, ix0 = tx * TXC;
-    const size_t plane_bytes = (size_t)p.H * c8s_row_bytes<true>(p.W);  // input rows are C8SP
-    const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
+    const int tiles_img = p.tiles_x * p.tiles_y;
+    const int total = p.N * tiles_img;
+    const size_t row_bytes = c8s_row_bytes<true>(p.W);  // input rows are C8SP
+    const size_t plane_bytes = (size_t)p.H * row_bytes;
 
-    long hsrc[MAXP];
+    // this thread's pieces of a stage: (plane-in-group/half, halo row, halo column); clamped duplicates past the end
+    int pc_r[MAXP], pc_x[MAXP], pc_ghl[MAXP];
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         int pc = (wave + i * NW) * 64 + lane;
-        pc = pc < HALO_PIECES ? pc : HALO_PIECES - 1;
-        const int ghl = pc / PLANE_PIECES;
-        const int rem = pc - ghl * PLANE_PIECES;
-        const int r = rem / WH, x = rem - r * WH;
-        const int sy = iy0 - DHI + r, sx = ix0 - DHI + x;
-        const bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
-        hsrc[i] = ok ? (long)(ghl >> 1) * (long)plane_bytes + (long)sy * (long)c8s_row_bytes<true>(p.W) +
-                           (long)c8s_piece<true>(sx) + (ghl & 1) * 512
-                     : -1;
+        pc = pc < G::HALO_PIECES ? pc : G::HALO_PIECES - 1;
+        pc_ghl[i] = pc / PLANE_PIECES;
+        const int rem = pc - pc_ghl[i] * PLANE_PIECES;
+        pc_r[i] = rem / WH;
+        pc_x[i] = rem - pc_r[i] * WH;
     }
-    auto issue = [&](int q, char *buf) {
-        const char *base = in_n + (size_t)(4 * q) * plane_bytes;
+    // stage `step` of this block: tile = blockIdx.x + (step / nq) * gridDim.x, channel group q = step % nq
+    auto issue = [&](int step) {
+        const int it = step / nq, q = step - it * nq;
+        const long t = (long)blockIdx.x + (long)it * gridDim.x;
+        char *buf = smem + (step % DEPTH) * STAGE_BYTES;
+        const bool live = t < total;
+        const int tt = live ? (int)t : 0;
+        const int n = tt / tiles_img, rem = tt - n * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const char *base = (const char *)p.in + ((size_t)n * p.in_planes + 4 * q) * plane_bytes;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
-            const int j = wave + i * NW;
-            if (j < HALO_INSTR)
-                glds16(hsrc[i] >= 0 ? (const void *)(base + hsrc[i]) : (const void *)p.zero, buf + j * 1024);
+            const int sy = ty * NW - DHI + pc_r[i], sx = tx * G::TXC - DHI + pc_x[i];
+            const bool ok = live && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+            const char *src = base + (size_t)(pc_ghl[i] >> 1) * plane_bytes + (size_t)sy * row_bytes +
+                              c8s_piece<true>(sx) + (pc_ghl[i] & 1) * 512;
+            glds16(ok ? (const void *)src : (const void *)p.zero, buf + (wave + i * NW) * 1024);
         }
     };
-    issue(0, smem);
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) issue(d);
     const int w_bytes = NB * NB * nq * 2048;
     for (int i = threadIdx.x; i < w_bytes / 16; i += NW * 64)
         *(f32x4 *)(wbuf + i * 16) = *(const f32x4 *)((const char *)p.wp + i * 16);
+    const float bias = (p.bias && g < p.cout) ? p.bias[g] : 0.0f;
 
     f32x4 acc[NT];
+    int step = 0;
+    for (long t = blockIdx.x; t < total; t += gridDim.x) {
+        const int n = (int)t / tiles_img, rem = (int)t - n * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = (p.bias && g < p.cout) ? p.bias[g] : 0.0f;
-
-    for (int q = 0; q < nq; ++q) {
-        wait_vm0();
-        __syncthreads();
-        char *cur = smem + (q & 1) * STAGE_BYTES;
-        if (q + 1 < nq) issue(q + 1, smem + ((q + 1) & 1) * STAGE_BYTES);
+            for (int r = 0; r < 4; ++r) acc[tt][r] = bias;
+        for (int q = 0; q < nq; ++q, ++step) {
+            // oldest outstanding stage (this one) has landed once at most DEPTH-2 younger stages remain in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXP * (DEPTH - 2)) : "memory");
+            __syncthreads();  // ... for every wave's pieces; and slot (step-1) % DEPTH is free again
+            issue(step + DEPTH - 1);
+            const char *cur = smem + (step % DEPTH) * STAGE_BYTES;
 #pragma unroll
-        for (int nd = 0; nd < NB; ++nd)
+            for (int nd = 0; nd < NB; ++nd)
 #pragma unroll
-            for (int ndx = 0; ndx < NB; ++ndx) {
-                const int hr = wave - (DLO + nd) + DHI;
-                const int hx = col - (DLO + ndx) + DHI;
-                const char *wq = wbuf + (((nd * NB + ndx) * nq + q) * 2) * 1024 + lane * 16;
-                const f16x8 ah = *(const f16x8 *)(wq);
-                const f16x8 al = *(const f16x8 *)(wq + 1024);
-                const char *hb = cur + (((2 * g) * HR + hr) * WH + hx) * 16;
+                for (int ndx = 0; ndx < NB; ++ndx) {
+                    const int hr = wave - (DLO + nd) + DHI;
+                    const int hx = col - (DLO + ndx) + DHI;
+                    const char *wq = wbuf + (((nd * NB + ndx) * nq + q) * 2) * 1024 + lane * 16;
+                    const f16x8 ah = *(const f16x8 *)(wq);
+                    const f16x8 al = *(const f16x8 *)(wq + 1024);
+                    const char *hb = cur + (((2 * g) * HR + hr) * WH + hx) * 16;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f16x8 bh = *(const f16x8 *)(hb + t * 256);
-                    const f16x8 bl = *(const f16x8 *)(hb + t * 256 + PLANE_PIECES * 16);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
+                    for (int tt = 0; tt < NT; ++tt) {
+                        const f16x8 bh = *(const f16x8 *)(hb + tt * 256);
+                        const f16x8 bl = *(const f16x8 *)(hb + tt * 256 + PLANE_PIECES * 16);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[tt], 0, 0, 0);
+                    }
                 }
-            }
-    }
-    const int iy = iy0 + wave;
-    if (iy < p.H && g < p.cout) {
+        }
+        const int iy = ty * NW + wave;
+        if (iy < p.H && g < p.cout) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int ix = ix0 + 16 * t + col;
-            if (ix < p.W) {
+            for (int tt = 0; tt < NT; ++tt) {
+                const int ix = tx * G::TXC + 16 * tt + col;
+                if (ix < p.W) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int oy = 2 * iy + (r >> 1), ox = 2 * ix + (r & 1);
-                    if (p.outfmt == OUT_U8HWC) {
-                        float v = acc[t][r] * 255.0f;
-                        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
-                        ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + g] = (uint8_t)v;
-                    } else {
-                        ((float *)p.out)[(((size_t)n * p.cout + g) * p.OH + oy) * p.OW + ox] = acc[t][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int oy = 2 * iy + (r >> 1), ox = 2 * ix + (r & 1);
+                        if (p.outfmt == OUT_U8HWC) {
+                            float v = acc[tt][r] * 255.0f;
+                            v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+                            ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + g] = (uint8_t)v;
+                        } else {
+                            ((float *)p.out)[(((size_t)n * p.cout + g) * p.OH + oy) * p.OW + ox] = acc[tt][r];
+                        }
                     }
                 }
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the ring's look-ahead before the LDS is released
 }
 
 // fp32 NCHW -> split rows (module boundary / latents into the synthesis track); SP: C8SP rows, else C8S

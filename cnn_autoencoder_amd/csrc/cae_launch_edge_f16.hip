@@ -55,25 +55,35 @@ int launch_first_f16(int ks, int ct, bool gdn, const LayerArgs &a, const FirstAr
     return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
 }
 
-template <int KS>
+template <int KS, int NW, int DEPTH>
 static int launch_last_f16_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = 4;
-    constexpr int P = KS / 2;
-    constexpr int NB = (KS - 1 - P) / 2 + (P + 1) / 2 + 1;
-    constexpr int HALO_INSTR = (8 * (NW + NB - 1) * (32 + NB - 1) + 63) / 64;
-    const int lds = 2 * HALO_INSTR * 1024 + NB * NB * a.cci * 2048;
+    using G = LastGeomF16<KS, NW, DEPTH>;
+    const int lds = G::lds_bytes(a.cci);
     if (lds > 160 * 1024) return fail(CAE_ERR_UNSUPPORTED, "last-layer weights do not fit the LDS");
-    auto kern = deconv_last_f16_kernel<KS, NW>;
-    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
+    auto kern = deconv_last_f16_kernel<KS, NW, DEPTH>;
+    static bool attr_done = false;
+    static int n_cu = 0;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_done = true;
+    }
+    LayerArgs b = a;
+    b.tiles_x = (a.W + G::TXC - 1) / G::TXC;
+    b.tiles_y = (a.H + NW - 1) / NW;
+    const size_t total = (size_t)b.N * b.tiles_x * b.tiles_y;
+    if (total > 0x7fffffff) return fail(CAE_ERR_ARG, "batch too large");
+    const unsigned grid = (unsigned)std::min<size_t>(total, (size_t)std::max(n_cu, 1));  // persistent
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, b);
     HIP_TRY(hipGetLastError());
     return CAE_OK;
 }
 
 int launch_last_f16(int ks, const LayerArgs &a, hipStream_t st) {
-    if (ks == 3) return launch_last_f16_t<3>(a, st);
-    if (ks == 5) return launch_last_f16_t<5>(a, st);
+    if (ks == 3) return launch_last_f16_t<3, 8, 3>(a, st);  // 3 x 40 KiB ring + 32 KiB weights (128 channels)
+    if (ks == 5) return launch_last_f16_t<5, 4, 2>(a, st);  // 3x3 neighbours: 72 KiB of weights, shallower ring
     return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
 }
 
