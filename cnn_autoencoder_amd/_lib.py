@@ -39,6 +39,8 @@ SYMBOLS = {
     'cae_synthesis': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'cae_gdn_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_quantize': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'cae_quantize_export': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    'cae_copy_to_host': (c_int, [c_void_p, c_void_p, c_size_t]),
     'cae_dequantize': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'cae_model_set_density': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float]),
     'cae_likelihood': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

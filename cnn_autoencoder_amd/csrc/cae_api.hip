@@ -988,6 +988,35 @@ int cae_likelihood(cae_model_t *mm, const float *latents, int n, int hw, float *
     return CAE_OK;
 }
 
+int cae_quantize_export(cae_model_t *mm, const float *latents, int n, int hw, int32_t *symbols_host, int max_blocks,
+                        void *stream) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !latents || !symbols_host) return fail(CAE_ERR_ARG, "NULL argument");
+    if (m->ent.channels == 0) return fail(CAE_ERR_ARG, "entropy model not set");
+    if (n < 1 || hw < 1) return fail(CAE_ERR_ARG, "bad shape");
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        int rc = m->ensure_device();
+        if (rc) return rc;
+    }
+    const size_t total = (size_t)n * m->c_bn * hw;
+    // few, fat workgroups: a CU that hosts an export workgroup cannot host a workgroup of the register-file-filling
+    // conv / deconv kernels, so the link is kept busy from as few CUs as possible
+    const unsigned cap = (unsigned)std::max(max_blocks, 1);
+    if (hw % 4 == 0 && (((uintptr_t)latents | (uintptr_t)symbols_host) & 15) == 0) {
+        const size_t total4 = total / 4;
+        const unsigned blocks = (unsigned)std::min<size_t>((total4 + 1023) / 1024, (size_t)cap);
+        hipLaunchKernelGGL(quantize_export4_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, latents,
+                           m->medians_dev, symbols_host, m->c_bn, hw / 4, total4);
+    } else {
+        const unsigned blocks = (unsigned)std::min<size_t>((total + 1023) / 1024, (size_t)cap);
+        hipLaunchKernelGGL(quantize_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, latents, m->medians_dev,
+                           symbols_host, m->c_bn, hw, total);
+    }
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
 int cae_dequantize(cae_model_t *mm, const int32_t *symbols, int n, int hw, float *latents, void *stream) {
     Model *m = reinterpret_cast<Model *>(mm);
     if (!m || !latents || !symbols) return fail(CAE_ERR_ARG, "NULL argument");

@@ -860,6 +860,33 @@ static __global__ void quantize_kernel(const float *y, const float *medians, int
     }
 }
 
+// The same quantiser for the PCIe export (cae_quantize_export): 16 elements per thread and iteration (four 16-byte
+// loads in flight, then four 16-byte stores), so that a handful of workgroups keeps the link busy.  HW % 4 == 0.
+static __global__ void __launch_bounds__(1024)
+quantize_export4_kernel(const float *y, const float *medians, int32_t *sym, int C, int HW4, size_t total4) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total4; i0 += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = i0 + k * stride;
+            if (i < total4) v[k] = ((const f32x4 *)y)[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = i0 + k * stride;
+            if (i < total4) {
+                const float med = medians[(i / HW4) % C];
+                i32x4 q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = (int32_t)rintf(v[k][e] - med);
+                ((i32x4 *)sym)[i] = q;
+            }
+        }
+    }
+}
+
 // y_hat = float(symbols) + median_c                (EntropyModel.dequantize)
 static __global__ void dequantize_kernel(const int32_t *sym, const float *medians, float *y, int C, int HW, size_t total) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {

@@ -302,6 +302,23 @@ class EntropyBottleneck(nn.Module):
         return sym
 
     @torch.no_grad()
+    def quantize_export(self, x: torch.Tensor, out_pinned: torch.Tensor, max_blocks: int = 32) -> None:
+        """Quantise (B,C,...) latents on the current stream straight into a pinned host int32 tensor of the same
+        number of elements (cae_quantize_export): the symbols cross PCIe from a few workgroups beside the
+        compute kernels.  Synchronise the stream before reading ``out_pinned``."""
+        dev = _lib.require_gpu()
+        h = self._sync_handle()
+        if x.dim() < 3 or x.size(1) != self.channels:
+            raise ValueError(f'Invalid input shape {tuple(x.shape)} for {self.channels} channels')
+        if (not out_pinned.is_pinned() or out_pinned.dtype != torch.int32 or out_pinned.numel() != x.numel()
+                or not out_pinned.is_contiguous()):
+            raise ValueError('out_pinned must be a contiguous pinned int32 tensor with one element per latent')
+        x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        hw = int(np.prod(x.shape[2:]))
+        _lib.check(_lib.lib().cae_quantize_export(h.ptr, x.data_ptr(), x.size(0), hw, out_pinned.data_ptr(),
+                                                  int(max_blocks), _lib.stream_ptr()))
+
+    @torch.no_grad()
     def dequantize_symbols(self, sym: torch.Tensor) -> torch.Tensor:
         """(B,C,...) int32 symbols on the GPU -> float latents symbols + median (HIP kernel)."""
         dev = _lib.require_gpu()

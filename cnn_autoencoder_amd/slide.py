@@ -90,6 +90,7 @@ class SlideCoder:
         self.eb = _module(codec._model['fact_ent'])
         self.level = len(self.dec.synthesis_track)
         self.coder_threads = coder_threads
+        self.export_blocks = 32  # workgroups of the PCIe export kernel (cae_quantize_export)
         self._pinned = {}
         self._copy_stream = None
         self.timers = {}
@@ -146,6 +147,7 @@ class SlideCoder:
         B = rANS encode + decode (host worker), D = H2D+dequantise+synthesis+SSE (GPU)."""
         import time
         from concurrent.futures import ThreadPoolExecutor
+        from . import _lib
         dev = batches[0].device
         main = torch.cuda.current_stream(dev)
         if self._copy_stream is None:
@@ -166,16 +168,14 @@ class SlideCoder:
             pin = self._pin(('a', k % 3), (n, C, hw), torch.int32)
             ready = torch.cuda.Event()
             ready.record(main)
-            with torch.cuda.stream(copy):
-                copy.wait_event(ready)
-                pin.copy_(sym.reshape(n, C, hw), non_blocking=True)
-                done = torch.cuda.Event()
-                done.record(copy)
-            sym.record_stream(copy)
-            return k, pin, done, hw
+            return k, pin, ready, hw, sym
 
-        def host_encode(k, pin, done, hw):
-            done.synchronize()
+        def host_encode(k, pin, ready, hw, sym):
+            # D2H on the DMA engines from this worker thread (cae_copy_to_host): a hipMemcpyAsync here runs as a
+            # blit kernel under PyTorch's HIP runtime and held the main stream up for the whole PCIe transfer
+            ready.synchronize()
+            _lib.check(_lib.lib().cae_copy_to_host(pin.data_ptr(), sym.data_ptr(), sym.numel() * 4))
+            del sym
             t0 = time.perf_counter()
             payloads = self.eb.encode_symbols(pin.numpy(), self.coder_threads)
             return k, payloads, hw, pin.shape, time.perf_counter() - t0

@@ -114,6 +114,15 @@ int cae_gdn_forward(cae_model_t *m, int track, int index, const float *x_dev, in
 int cae_quantize(cae_model_t *m, const float *latents_dev, int n, int hw, int32_t *symbols_dev, void *stream);
 int cae_dequantize(cae_model_t *m, const int32_t *symbols_dev, int n, int hw, float *latents_dev, void *stream);
 
+/* The same quantiser writing the symbols straight into PINNED HOST memory (a device-accessible host
+ * pointer, e.g. hipHostMalloc / a pinned torch tensor) from at most `max_blocks` workgroups: the PCIe
+ * transfer then runs beside the compute kernels of another stream on a few CUs.  (A hipMemcpyAsync D2H
+ * here ran as a blit kernel that filled every CU's wave slots for the 1.8 ms the 100 MB take to cross
+ * PCIe and stalled the next layer's kernels for that long; profiles/r01_experiments.md.)  The caller
+ * synchronises `stream` (or an event on it) before reading the symbols on the host. */
+int cae_quantize_export(cae_model_t *m, const float *latents_dev, int n, int hw, int32_t *symbols_pinned_host,
+                        int max_blocks, void *stream);
+
 /* Density network of the factorized prior (compressai EntropyBottleneck parameters `_matrix{i}`,
  * `_bias{i}`, `_factor{i}`, i = 0..n_filters; the reference builds it at _autoencoders.py:476-477 with
  * filters = [r]*K).  The caller passes EFFECTIVE values: matrices[i] = softplus(_matrix{i})
@@ -133,6 +142,12 @@ int cae_model_set_density(cae_model_t *m, int channels, int n_filters, const int
  * set_density.  Calls on one handle must be stream-ordered. */
 int cae_likelihood(cae_model_t *m, const float *latents_dev, int n, int hw, float *y_hat_dev,
                    float *likelihood_dev, double *bits_dev, void *stream);
+
+/* Blocking device -> pinned-host copy on the DMA engines (hsa_amd_memory_async_copy), for symbols on their way
+ * to the host coder.  The caller has already waited for the kernels that produce `src_dev` (event / stream
+ * synchronise); safe to call from any host thread.  hipMemcpyAsync is not used because the HIP runtime bundled
+ * with PyTorch-ROCm 7.0 runs D2H copies as a blit kernel that occupies the CUs for the whole PCIe transfer. */
+int cae_copy_to_host(void *dst_pinned_host, const void *src_dev, size_t bytes);
 
 /* Per-tile sum of squared differences of two (n, elems) uint8 batches -> sse_dev[n] (float64).
  * The distortion half of the per-tile statistics record the slide driver all-gathers (the
