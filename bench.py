@@ -99,8 +99,8 @@ def cpu_baseline(state, cfg, tiles, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=32)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=96)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--tile', type=int, default=1024)
     ap.add_argument('--batch', type=int, default=32, help='tiles per step per GPU')
     ap.add_argument('--distinct', type=int, default=4, help='distinct synthetic tiles per rank (tiled to the batch)')
@@ -192,7 +192,7 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))[args.precision]
-            keys = {'fp32': {'analysis.1': 'conv_s2_kernel<3, 4, 4, true>@4194304',
+            keys = {'fp32': {'analysis.1': 'conv_s2_kernel<3, 4, 4, true, 2, false>@4194304',
                              'synthesis.2': 'deconv_s2_kernel<3, 4, 4, true>@4194304'},
                     'f16x3': {'analysis.1': 'conv_s2_f16_kernel<3, 4, true>@2097152',
                               'synthesis.2': 'deconv_s2_f16_kernel<3, 4, 8, 1, true>@4194304'}}[args.precision]
