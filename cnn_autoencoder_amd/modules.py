@@ -75,10 +75,17 @@ class _ConvParams(nn.Module):
 
     transposed = False
 
-    def __init__(self, channels_in: int, channels_out: int, kernel_size: int, bias: bool):
+    def __init__(self, channels_in: int, channels_out: int, kernel_size: int, bias: bool, groups: int = 1):
         super().__init__()
         self.in_channels, self.out_channels, self.kernel_size = channels_in, channels_out, kernel_size
-        shape = ((channels_in, channels_out) if self.transposed else (channels_out, channels_in))
+        self.groups = int(groups)
+        if channels_in % self.groups != 0:
+            raise ValueError('in_channels must be divisible by groups')
+        if channels_out % self.groups != 0:
+            raise ValueError('out_channels must be divisible by groups')
+        # parameter shapes of nn.Conv2d / nn.ConvTranspose2d with `groups` (state-dict compatible)
+        shape = ((channels_in, channels_out // self.groups) if self.transposed
+                 else (channels_out, channels_in // self.groups))
         self.weight = nn.Parameter(torch.empty(*shape, kernel_size, kernel_size))
         self.bias = nn.Parameter(torch.empty(channels_out)) if bias else None
         # default nn.Conv2d init first (keeps the RNG stream aligned with the reference ctor) ...
@@ -87,6 +94,25 @@ class _ConvParams(nn.Module):
             fan_in = self.weight.size(1) * kernel_size * kernel_size
             bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
             nn.init.uniform_(self.bias, -bound, bound)
+
+    def dense_weight(self) -> torch.Tensor:
+        """Weight of the equivalent groups=1 layer: (cout,cin,k,k), transposed (cin,cout,k,k).  A grouped layer is
+        the dense one with a block-diagonal channel matrix; the dense MFMA kernels then compute it exactly (the
+        zero products add 0.0), at the dense layer's cost."""
+        w = self.weight.detach().float()
+        if self.groups == 1:
+            return w
+        g, k = self.groups, self.kernel_size
+        cin_g, cout_g = self.in_channels // g, self.out_channels // g
+        if self.transposed:
+            dense = w.new_zeros(self.in_channels, self.out_channels, k, k)
+            for j in range(g):
+                dense[j * cin_g:(j + 1) * cin_g, j * cout_g:(j + 1) * cout_g] = w[j * cin_g:(j + 1) * cin_g]
+        else:
+            dense = w.new_zeros(self.out_channels, self.in_channels, k, k)
+            for j in range(g):
+                dense[j * cout_g:(j + 1) * cout_g, j * cin_g:(j + 1) * cin_g] = w[j * cout_g:(j + 1) * cout_g]
+        return dense
 
     def forward(self, x):
         raise NotImplementedError('layers run fused: call the owning Analyzer / Synthesizer')
@@ -127,11 +153,26 @@ def _define_act_layer(act_layer_type, channels_in=None, track='analysis'):
 def _check_variant(kernel_size, groups, batch_norm, dropout, use_residual, act_layer_type, channels_expansion):
     if act_layer_type not in (None, 'GDN', 'LeakyReLU', 'ReLU'):
         raise ValueError(f'Activation layer {act_layer_type} not supported')
-    if groups or batch_norm or use_residual or channels_expansion != 1:
-        raise NotImplementedError('groups / batch_norm / use_residual / channels_expansion variants are not built yet')
+    if use_residual:
+        raise NotImplementedError('use_residual units are not built yet')
     if kernel_size not in (3, 5):
         raise NotImplementedError('kernel_size must be 3 or 5')
-    del dropout  # Dropout2d is the identity in eval mode
+    if int(channels_expansion) < 1:
+        raise ValueError('channels_expansion must be >= 1')
+    del groups, batch_norm, dropout  # grouped / batch-normalised layers are folded on upload; Dropout2d is the identity in eval
+
+
+def _fold_batch_norm(w: torch.Tensor, b: Optional[torch.Tensor], bn: Optional[nn.BatchNorm2d], transposed: bool):
+    """Eval-mode BatchNorm2d behind a convolution = the same convolution with scaled weights and a shifted bias
+    (running statistics; the codec path is inference only)."""
+    if bn is None:
+        return w, None if b is None else b.detach().float()
+    if bn.training:
+        raise NotImplementedError('BatchNorm2d in training mode (batch statistics) is not built: call .eval()')
+    scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps))
+    w = w * (scale.view(1, -1, 1, 1) if transposed else scale.view(-1, 1, 1, 1))
+    b0 = torch.zeros_like(scale) if b is None else b.detach().float()
+    return w, (b0 - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
 
 
 class _Unit(nn.Module):
@@ -145,17 +186,26 @@ class _Unit(nn.Module):
                  bias=False, act_layer_type=None):
         super().__init__()
         model = []
-        self.pre_index = self.gdn_index = None
+        self.pre_index = self.gdn_index = self.pre_bn_index = self.main_bn_index = None
+        g = channels_in if groups else 1
         if act_layer_type is not None and act_layer_type not in ['GDN']:
             self.pre_index = 0
-            model.append(self._conv_cls(channels_in, channels_in, kernel_size, bias))
+            model.append(self._conv_cls(channels_in, channels_in, kernel_size, bias, g))
+            if batch_norm:
+                self.pre_bn_index = len(model)
+                model.append(nn.BatchNorm2d(channels_in, affine=True))
             model.append(_define_act_layer(act_layer_type, channels_in, track=self._track))
         self.main_index = len(model)
-        model.append(self._conv_cls(channels_in, channels_out, kernel_size, bias))
+        model.append(self._conv_cls(channels_in, channels_out, kernel_size, bias, g))
+        if batch_norm:
+            self.main_bn_index = len(model)
+            model.append(nn.BatchNorm2d(channels_out, affine=True))
         if act_layer_type is not None:
             if act_layer_type == 'GDN':
                 self.gdn_index = len(model)
             model.append(_define_act_layer(act_layer_type, channels_out, track=self._track))
+        if dropout > 0.0:
+            model.append(nn.Dropout2d(dropout))
         self.act_code = _ACT_CODES[act_layer_type]
         self.model = nn.Sequential(*model)
 
@@ -170,6 +220,17 @@ class _Unit(nn.Module):
     @property
     def gdn(self):
         return None if self.gdn_index is None else self.model[self.gdn_index]
+
+    def effective_main(self):
+        """(dense weight, bias | None) of the strided layer with groups expanded and BatchNorm folded."""
+        conv = self.main
+        bn = None if self.main_bn_index is None else self.model[self.main_bn_index]
+        return _fold_batch_norm(conv.dense_weight(), conv.bias, bn, conv.transposed)
+
+    def effective_pre(self):
+        conv = self.pre
+        bn = None if self.pre_bn_index is None else self.model[self.pre_bn_index]
+        return _fold_batch_norm(conv.dense_weight(), conv.bias, bn, conv.transposed)
 
 
 class DownsamplingUnit(_Unit):
@@ -212,13 +273,16 @@ class _Track(nn.Module):
             raise ValueError(f"precision must be 'fp32' or 'f16x3', got {prec!r}")
         if any(u.act_code for u in self._units()):
             return 0  # LeakyReLU / ReLU units (stride-1 pre-convolutions) are built on the fp32 kernels
+        if any(u.gdn is not None and u.main.out_channels > 128 for u in self._units()):
+            return 0  # the f16x3 GDN epilogue covers up to 128 channels
         return 1 if prec == 'f16x3' else 0
 
     def _units(self):
         return list(getattr(self, self._track_attr))
 
     def _param_versions(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # buffers too (BatchNorm running statistics), and the mode: BatchNorm is folded in eval mode only
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers())) + (self.training,)
 
     def _sync(self) -> _lib.Handle:
         _lib.require_gpu()
@@ -231,8 +295,9 @@ class _Track(nn.Module):
             with torch.no_grad():
                 for i, unit in enumerate(self._units()):
                     conv = unit.main
-                    w = np.ascontiguousarray(conv.weight.detach().float().cpu().numpy())
-                    b = None if conv.bias is None else np.ascontiguousarray(conv.bias.detach().float().cpu().numpy())
+                    wt, bt = unit.effective_main()
+                    w = np.ascontiguousarray(wt.cpu().numpy(), dtype=np.float32)
+                    b = None if bt is None else np.ascontiguousarray(bt.detach().float().cpu().numpy())
                     beta = gamma = None
                     if unit.gdn is not None:
                         be, ga = unit.gdn.effective()
@@ -245,9 +310,10 @@ class _Track(nn.Module):
                     if unit.act_code or unit.pre is not None:
                         pw = pb = None
                         if unit.pre is not None:
-                            pw = np.ascontiguousarray(unit.pre.weight.detach().float().cpu().numpy())
-                            if unit.pre.bias is not None:
-                                pb = np.ascontiguousarray(unit.pre.bias.detach().float().cpu().numpy())
+                            pwt, pbt = unit.effective_pre()
+                            pw = np.ascontiguousarray(pwt.cpu().numpy(), dtype=np.float32)
+                            if pbt is not None:
+                                pb = np.ascontiguousarray(pbt.detach().float().cpu().numpy())
                         _lib.check(L.cae_model_set_layer_act(
                             self._handle.ptr, self._track_id, i, unit.act_code,
                             None if pw is None else pw.ctypes.data, None if pb is None else pb.ctypes.data))
@@ -293,6 +359,7 @@ class Analyzer(_Track):
             down_track.append(DownsamplingUnit(prev, curr, kernel_size, groups, batch_norm, dropout, bias,
                                                act_layer_type))
             prev = curr
+            curr = prev * channels_expansion  # reference channel plan (_autoencoders.py:330-342)
         down_track.append(DownsamplingUnit(prev, channels_bn, kernel_size, groups, batch_norm, dropout, bias, None))
         self.analysis_track = nn.Sequential(*down_track)
         self.apply(initialize_weights)
@@ -347,10 +414,12 @@ class Synthesizer(_Track):
         if compression_level < 1:
             raise NotImplementedError('compression_level must be >= 1')
         up_track = []
-        prev, curr = channels_bn, channels_net
+        # reference channel plan (_autoencoders.py:385-400): starts at net * e^L and divides by e per level
+        prev, curr = channels_bn, channels_net * channels_expansion ** compression_level
         for _ in range(compression_level - 1):
             up_track.append(UpsamplingUnit(prev, curr, kernel_size, groups, batch_norm, dropout, bias, act_layer_type))
             prev = curr
+            curr = prev // channels_expansion
         up_track.append(UpsamplingUnit(prev, channels_org, kernel_size, groups, batch_norm, dropout, bias, None))
         self.synthesis_track = nn.Sequential(*up_track)
         color_layers = [nn.Sequential(NoneColorLayer()) for _ in range(compression_level - 1)]
@@ -376,8 +445,8 @@ class Synthesizer(_Track):
         brg: List[torch.Tensor] = []
         brg_ptr = None
         if bridges and L > 1:
-            brg = [torch.empty((n, self._dims[1], lh * 2 ** (i + 1), lw * 2 ** (i + 1)), dtype=torch.float32,
-                               device=dev) for i in range(L - 1)]
+            brg = [torch.empty((n, u.main.out_channels, lh * 2 ** (i + 1), lw * 2 ** (i + 1)), dtype=torch.float32,
+                               device=dev) for i, u in enumerate(self._units()[:-1])]
             brg_ptr = (ctypes.c_void_p * (L - 1))(*[b.data_ptr() for b in brg])
         _lib.check(_lib.lib().cae_synthesis(hd.ptr, x.data_ptr(), n, lh, lw, out.data_ptr(), fmt, brg_ptr,
                                             _lib.stream_ptr()))

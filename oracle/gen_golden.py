@@ -130,6 +130,49 @@ def make_case(ref, name, cfg, tile, seed, store_weights, store_layers):
           '|y|max %.3f' % y.abs().max().item(), 'size %.1f KB' % (os.path.getsize(os.path.join(GOLD, name + '.npz')) / 1024))
 
 
+def make_variant_case(ref, name, kw, tile, seed):
+    """Variants whose parameters are not produced by synth.synthetic_state (BatchNorm, groups, channel expansion,
+    multiscale colour layers): the reference builds the modules under torch.manual_seed(seed), BatchNorm gets
+    non-trivial affine parameters and running statistics, and the fixture stores every state-dict tensor next to
+    the reference's eval-mode outputs.  (GDN arithmetic is the oracle's, as in make_case.)"""
+    torch.manual_seed(seed)
+    enc = ref.Analyzer(**kw)
+    dec = ref.Synthesizer(**kw)
+    g = torch.Generator().manual_seed(seed + 1)
+    for mod in list(enc.modules()) + list(dec.modules()):
+        if isinstance(mod, nn.BatchNorm2d):
+            with torch.no_grad():
+                mod.weight.uniform_(0.5, 1.5, generator=g)
+                mod.bias.uniform_(-0.2, 0.2, generator=g)
+                mod.running_mean.uniform_(-0.2, 0.2, generator=g)
+                mod.running_var.uniform_(0.5, 1.5, generator=g)
+    enc.eval()
+    dec.eval()
+    out = {}
+    with torch.no_grad():
+        x = O.tile_to_input(tile)
+        y = enc(x)
+        yq = torch.round(y)
+        x_r, brg = dec(yq)
+    out['tile'] = tile
+    out['y'] = y.numpy()
+    for i, t in enumerate(x_r):
+        if t is not None:
+            out[f'x_r_{i}'] = t.numpy()
+    out['x_r_none'] = np.array([t is None for t in x_r])
+    for i, t in enumerate(brg):
+        out[f'brg_stats_{i}'] = stats(t)
+        out[f'brg_shape_{i}'] = np.array(t.shape)
+    for k, v in enc.state_dict().items():
+        out['encoder/' + k] = v.numpy()
+    for k, v in dec.state_dict().items():
+        out['decoder/' + k] = v.numpy()
+    out['cfg_json'] = np.frombuffer(json.dumps(dict(kw, seed=seed)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **out)
+    print(name, 'y', tuple(y.shape), 'x_r', [None if t is None else tuple(t.shape) for t in x_r],
+          'size %.1f KB' % (os.path.getsize(os.path.join(GOLD, name + '.npz')) / 1024))
+
+
 def make_init_fixture(ref):
     """Pins initialize_weights (_autoencoders.py:37-42) and the state-dict key list."""
     torch.manual_seed(0)
@@ -167,6 +210,20 @@ def main():
     make_case(ref, 'lrelu_bias_small_40x56', dict(small, act_layer_type='LeakyReLU', bias=True), synth.histo_tile(40, 6, 56), 21, True, True)
     make_case(ref, 'relu_small_37x45', dict(small, act_layer_type='ReLU'), rng.integers(0, 256, (37, 45, 3), dtype=np.uint8), 22, True, True)
     make_case(ref, 'lrelu_k5_mid_48x48', dict(small, act_layer_type='LeakyReLU', kernel_size=5, channels_net=40, channels_bn=24), synth.histo_tile(48, 7), 23, False, False)
+    # variants folded on upload: BatchNorm (eval), grouped (depthwise) layers, channel expansion
+    vk = dict(channels_org=3, channels_net=8, channels_bn=16, compression_level=3, channels_expansion=1, kernel_size=3,
+              groups=False, batch_norm=False, dropout=0.0, bias=False, use_residual=False, act_layer_type=None)
+    make_variant_case(ref, 'var_bn_gdn_40x56', dict(vk, batch_norm=True, act_layer_type='GDN'),
+                      synth.histo_tile(40, 8, 56), 31)
+    make_variant_case(ref, 'var_bn_lrelu_bias_37x45', dict(vk, batch_norm=True, bias=True, act_layer_type='LeakyReLU',
+                                                           dropout=0.25),
+                      np.random.default_rng(199).integers(0, 256, (37, 45, 3), dtype=np.uint8), 32)
+    make_variant_case(ref, 'var_expansion2_gdn_48x48', dict(vk, channels_net=4, channels_bn=24, channels_expansion=2,
+                                                            act_layer_type='GDN'), synth.histo_tile(48, 9), 33)
+    make_variant_case(ref, 'var_groups_relu_40x40', dict(vk, channels_net=3, channels_bn=3, groups=True, bias=True,
+                                                         act_layer_type='ReLU'), synth.histo_tile(40, 10), 34)
+    make_variant_case(ref, 'var_groups_k5_32x48', dict(vk, channels_net=3, channels_bn=3, groups=True, kernel_size=5),
+                      synth.histo_tile(32, 11, 48), 35)
     make_case(ref, 'gdn_canonical_64x64', synth.CANONICAL, synth.histo_tile(64, 4), 17, False, False)
     make_case(ref, 'gdn_canonical_96x80', synth.CANONICAL, rng.integers(0, 256, (96, 80, 3), dtype=np.uint8), 18, False, False)
 

@@ -81,6 +81,25 @@ def test_synthesis_matches_reference_golden(cae, name):
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
 
 
+@pytest.mark.parametrize('name', ['var_bn_gdn_40x56', 'var_bn_lrelu_bias_37x45', 'var_expansion2_gdn_48x48',
+                                  'var_groups_relu_40x40', 'var_groups_k5_32x48'])
+def test_variant_goldens(cae, name):
+    """BatchNorm (eval), grouped layers and channel expansion against the reference's own outputs."""
+    from test_host import variant_modules
+    g, cfg = load_golden(name)
+    enc, dec = variant_modules(cae, g, cfg)
+    x = torch.from_numpy(g['tile']).permute(2, 0, 1).unsqueeze(0).float() / 255.0
+    y = enc.cuda()(x.cuda()).cpu().numpy()
+    np.testing.assert_allclose(y, g['y'], rtol=RTOL, atol=ATOL)
+    x_r, brg = dec.cuda()(torch.round(torch.from_numpy(g['y'])).cuda())
+    np.testing.assert_allclose(x_r[0].cpu().numpy(), g['x_r_0'], rtol=RTOL, atol=ATOL)
+    assert all(t is None for t in x_r[1:])
+    assert [tuple(t.shape) for t in brg] == [tuple(g[f'brg_shape_{i}']) for i in range(len(brg))]
+    for i, t in enumerate(brg):
+        st = np.array([t.double().sum().item(), t.double().abs().sum().item(), (t.double() ** 2).sum().item()])
+        np.testing.assert_allclose(st, g[f'brg_stats_{i}'], rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize('inverse', [False, True])
 @pytest.mark.parametrize('channels', [16, 128, 192])
 def test_gdn_layer(cae, inverse, channels):
