@@ -270,6 +270,8 @@ Model::~Model() {
             if (l.wp_edge) (void)hipFree(l.wp_edge);
             if (l.pre_wp) (void)hipFree(l.pre_wp);
             if (l.pre_bias) (void)hipFree(l.pre_bias);
+            if (l.color_wp) (void)hipFree(l.color_wp);
+            if (l.color_bias) (void)hipFree(l.color_bias);
             if (l.wp16) (void)hipFree(l.wp16);
             if (l.gp16) (void)hipFree(l.gp16);
             if (l.wp_edge16) (void)hipFree(l.wp_edge16);
@@ -472,6 +474,30 @@ int cae_model_set_layer_act(cae_model_t *mm, int track, int index, int act, cons
     return CAE_OK;
 }
 
+int cae_model_set_color_layer(cae_model_t *mm, int index, int cin, int cout, const float *w, const float *bias) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !w) return fail(CAE_ERR_ARG, "NULL model or weight");
+    if (index < 0 || index >= m->L - 1) return fail(CAE_ERR_ARG, "colour layer index %d out of range", index);
+    if (cout < 1 || round_ct(cout) < 0 || round_ct(cin) < 0) return fail(CAE_ERR_UNSUPPORTED, "more than 192 channels not supported");
+    std::lock_guard<std::mutex> lk(m->mu);
+    Layer &l = m->dec[index];
+    if (!l.set) return fail(CAE_ERR_ARG, "set the synthesis layer before its colour layer");
+    if (cin != l.cout) return fail(CAE_ERR_ARG, "colour layer %d expects %d input channels, the level produces %d", index, cin, l.cout);
+    const int ct = round_ct(cout);
+    int rc = upload(pack_weights(w, false, cin, cout, m->ks, ct), &l.color_wp);
+    if (rc) return rc;
+    if (bias) {
+        std::vector<float> b(ct * 32, 0.0f);
+        std::copy(bias, bias + cout, b.begin());
+        if ((rc = upload(b, &l.color_bias))) return rc;
+    } else if (l.color_bias) {
+        (void)hipFree(l.color_bias);
+        l.color_bias = nullptr;
+    }
+    l.color_cout = cout;
+    return CAE_OK;
+}
+
 int cae_model_set_precision(cae_model_t *mm, int precision) {
     Model *m = reinterpret_cast<Model *>(mm);
     if (!m) return fail(CAE_ERR_ARG, "NULL model");
@@ -650,6 +676,11 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
 
 int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, void *out, int fmt,
                   float *const *bridges, void *stream) {
+    return cae_synthesis_multiscale(mm, latents, n, lh, lw, out, fmt, bridges, nullptr, stream);
+}
+
+int cae_synthesis_multiscale(cae_model_t *mm, const float *latents, int n, int lh, int lw, void *out, int fmt,
+                             float *const *bridges, float *const *colors, void *stream) {
     Model *m = reinterpret_cast<Model *>(mm);
     if (!m || !latents || !out) return fail(CAE_ERR_ARG, "NULL argument");
     if (n < 1 || lh < 1 || lw < 1) return fail(CAE_ERR_ARG, "bad latent batch %dx%dx%d", n, lh, lw);
@@ -771,6 +802,30 @@ int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, 
             if ((rc = launch_deconv(m->ks, l.ct, l.gdn, a, st))) return rc;
         }
         prof.end();
+        if (!last && colors && colors[i]) {  // colour layer of this level (_autoencoders.py:417-436, :448-449)
+            if (!l.color_wp) return fail(CAE_ERR_ARG, "colour layer %d not set", i);
+            if (f16) return fail(CAE_ERR_UNSUPPORTED, "multiscale colour layers run on the fp32 path: set precision 0");
+            LayerArgs c{};
+            c.in = (const float *)a.out;
+            c.out = colors[i];
+            c.wp = l.color_wp;
+            c.bias = l.color_bias;
+            c.zero = m->zero;
+            c.N = n;
+            c.H = a.OH;
+            c.W = a.OW;
+            c.OH = a.OH;
+            c.OW = a.OW;
+            c.in_planes = l.ct * 4;
+            c.cci = (l.cout + 7) / 8;
+            c.out_planes = round_ct(l.color_cout) * 4;
+            c.cout = l.color_cout;
+            c.tiles_x = (a.OW + 15) / 16;
+            c.tiles_y = (a.OH + 2 * CAE_CONV_NW - 1) / (2 * CAE_CONV_NW);
+            c.outfmt = OUT_NCHW;
+            c.act = 0;
+            if ((rc = launch_conv_s1(m->ks, round_ct(l.color_cout), false, c, st))) return rc;
+        }
         if (!last && bridges && bridges[i]) {
             const size_t t2 = (size_t)n * l.cout * a.OH * a.OW;
             if (f16)

@@ -23,6 +23,10 @@ struct Layer {
     // LeakyReLU / ReLU units: stride-1 convolution (cin -> cin) + activation in front of the strided one
     float *pre_wp = nullptr;   // packed weights of the pre-convolution, or null
     float *pre_bias = nullptr;
+    // multiscale colour layer on this synthesis level's output (stride-1 reflect conv to the image channels), or null
+    float *color_wp = nullptr;
+    float *color_bias = nullptr;
+    int color_cout = 0;
     int act = 0;               // activation after the pre-convolution and after this layer (0 none, 1 LeakyReLU, 2 ReLU)
     void *wp16 = nullptr;      // f16x3 path: packed hi/lo weights
     void *gp16 = nullptr;      // f16x3 path: packed hi/lo gamma

@@ -271,6 +271,8 @@ class _Track(nn.Module):
         prec = getattr(self, 'precision', None) or os.environ.get('CAE_PRECISION', 'f16x3')
         if prec not in ('fp32', 'f16x3'):
             raise ValueError(f"precision must be 'fp32' or 'f16x3', got {prec!r}")
+        if getattr(self, 'multiscale_analysis', False):
+            return 0  # colour layers are stride-1 convolutions on the fp32 kernels
         if any(u.act_code for u in self._units()):
             return 0  # LeakyReLU / ReLU units (stride-1 pre-convolutions) are built on the fp32 kernels
         if any(u.gdn is not None and u.main.out_channels > 128 for u in self._units()):
@@ -317,6 +319,15 @@ class _Track(nn.Module):
                         _lib.check(L.cae_model_set_layer_act(
                             self._handle.ptr, self._track_id, i, unit.act_code,
                             None if pw is None else pw.ctypes.data, None if pb is None else pb.ctypes.data))
+            if getattr(self, 'multiscale_analysis', False):
+                with torch.no_grad():
+                    for i, layer in enumerate(list(self.color_layers)[:-1]):
+                        conv = layer[0]
+                        cw = np.ascontiguousarray(conv.dense_weight().cpu().numpy(), dtype=np.float32)
+                        cb = None if conv.bias is None else np.ascontiguousarray(conv.bias.detach().float().cpu().numpy())
+                        _lib.check(L.cae_model_set_color_layer(self._handle.ptr, i, conv.in_channels,
+                                                               conv.out_channels, cw.ctypes.data,
+                                                               None if cb is None else cb.ctypes.data))
             self._versions = ver
         return self._handle
 
@@ -409,8 +420,7 @@ class Synthesizer(_Track):
                  act_layer_type=None, multiscale_analysis=False, **kwargs):
         super().__init__()
         _check_variant(kernel_size, groups, batch_norm, dropout, use_residual, act_layer_type, channels_expansion)
-        if multiscale_analysis:
-            raise NotImplementedError('multiscale_analysis colour layers are not built yet')
+        self.multiscale_analysis = bool(multiscale_analysis)
         if compression_level < 1:
             raise NotImplementedError('compression_level must be >= 1')
         up_track = []
@@ -422,14 +432,21 @@ class Synthesizer(_Track):
             curr = prev // channels_expansion
         up_track.append(UpsamplingUnit(prev, channels_org, kernel_size, groups, batch_norm, dropout, bias, None))
         self.synthesis_track = nn.Sequential(*up_track)
-        color_layers = [nn.Sequential(NoneColorLayer()) for _ in range(compression_level - 1)]
+        if multiscale_analysis:
+            # reference channel plan (_autoencoders.py:417-428): net * e^i, i descending; it matches the track's
+            # channels only for channels_expansion == 1 (checked when the weights are uploaded)
+            color_layers = [nn.Sequential(StridedReflectConv2d(channels_net * channels_expansion ** i, channels_org,
+                                                               kernel_size, bias, channels_org if groups else 1))
+                            for i in reversed(range(compression_level - 1))]
+        else:
+            color_layers = [nn.Sequential(NoneColorLayer()) for _ in range(compression_level - 1)]
         color_layers += [nn.Identity()]
         self.color_layers = nn.ModuleList(color_layers)
         self.rec_level = compression_level
         self.apply(initialize_weights)
         self._setup(channels_org, channels_net, channels_bn, compression_level, kernel_size)
 
-    def _run(self, x: torch.Tensor, fmt: int, bridges: bool):
+    def _run(self, x: torch.Tensor, fmt: int, bridges: bool, colors: bool = False):
         dev = _lib.require_gpu()
         hd = self._sync()
         if x.dim() != 4 or x.size(1) != self._dims[2]:
@@ -448,17 +465,24 @@ class Synthesizer(_Track):
             brg = [torch.empty((n, u.main.out_channels, lh * 2 ** (i + 1), lw * 2 ** (i + 1)), dtype=torch.float32,
                                device=dev) for i, u in enumerate(self._units()[:-1])]
             brg_ptr = (ctypes.c_void_p * (L - 1))(*[b.data_ptr() for b in brg])
-        _lib.check(_lib.lib().cae_synthesis(hd.ptr, x.data_ptr(), n, lh, lw, out.data_ptr(), fmt, brg_ptr,
-                                            _lib.stream_ptr()))
-        return out, brg
+        col: List[torch.Tensor] = []
+        col_ptr = None
+        if colors and self.multiscale_analysis and L > 1:
+            col = [torch.empty((n, self._dims[0], lh * 2 ** (i + 1), lw * 2 ** (i + 1)), dtype=torch.float32,
+                               device=dev) for i in range(L - 1)]
+            col_ptr = (ctypes.c_void_p * (L - 1))(*[c.data_ptr() for c in col])
+        _lib.check(_lib.lib().cae_synthesis_multiscale(hd.ptr, x.data_ptr(), n, lh, lw, out.data_ptr(), fmt, brg_ptr,
+                                                       col_ptr, _lib.stream_ptr()))
+        return out, brg, col
 
     def forward(self, x: torch.Tensor, bridges: bool = True):
-        """y_q (B,channels_bn,h,w) -> (x_r list [full-res, None, ...], fx_brg list) as the reference."""
-        out, brg = self._run(x, _lib.FMT_F32_NCHW, bridges)
-        x_r = [out] + [None] * (self._dims[3] - 1)
+        """y_q (B,channels_bn,h,w) -> (x_r list [full-res, half-res | None, ...], fx_brg list) as the reference:
+        x_r[0] is the reconstruction, x_r[j] the colour layer of level L-1-j (None without multiscale_analysis)."""
+        out, brg, col = self._run(x, _lib.FMT_F32_NCHW, bridges, colors=True)
+        x_r = [out] + (col[::-1] if col else [None] * (self._dims[3] - 1))
         return x_r, brg + [out]
 
     def forward_u8(self, x: torch.Tensor) -> torch.Tensor:
         """y_q -> (B,H,W,C) uint8 tiles; fuses the *255 / clip / truncate / HWC epilogue of codec.decode."""
-        out, _ = self._run(x, _lib.FMT_U8_HWC, False)
+        out, _, _ = self._run(x, _lib.FMT_U8_HWC, False)
         return out

@@ -103,6 +103,15 @@ int cae_analysis(cae_model_t *m, const void *tiles_dev, int fmt, int n, int h, i
 int cae_synthesis(cae_model_t *m, const float *latents_dev, int n, int lh, int lw,
                   void *out_dev, int fmt, float *const *bridges_dev, void *stream);
 
+/* Multiscale colour layers (Synthesizer(multiscale_analysis=True), _autoencoders.py:417-436): a stride-1 reflect
+ * convolution from the output of synthesis level `index` (< compression_level-1) to the image channels.
+ * w: (cout, cin, k, k).  cae_synthesis_multiscale additionally writes colors_dev[i] (n, cout, lh*2^(i+1),
+ * lw*2^(i+1)) float NCHW for every non-NULL entry: the reference's x_r[compression_level-1-i]
+ * (_autoencoders.py:446-452).  fp32 path only (precision 0). */
+int cae_model_set_color_layer(cae_model_t *m, int index, int cin, int cout, const float *w, const float *bias);
+int cae_synthesis_multiscale(cae_model_t *m, const float *latents_dev, int n, int lh, int lw, void *out_dev, int fmt,
+                             float *const *bridges_dev, float *const *colors_dev, void *stream);
+
 /* One GDN / IGDN layer on an NCHW tensor (compressai.layers.GDN.forward; reference call site
  * _autoencoders.py:29-30).  Uses the beta/gamma of layer `index` of `track`. */
 int cae_gdn_forward(cae_model_t *m, int track, int index, const float *x_dev, int n, int h, int w,

@@ -224,6 +224,11 @@ def main():
                                                          act_layer_type='ReLU'), synth.histo_tile(40, 10), 34)
     make_variant_case(ref, 'var_groups_k5_32x48', dict(vk, channels_net=3, channels_bn=3, groups=True, kernel_size=5),
                       synth.histo_tile(32, 11, 48), 35)
+    make_variant_case(ref, 'var_multiscale_lrelu_bias_40x56', dict(vk, bias=True, act_layer_type='LeakyReLU',
+                                                                   multiscale_analysis=True),
+                      synth.histo_tile(40, 12, 56), 36)
+    make_variant_case(ref, 'var_multiscale_gdn_k5_48x48', dict(vk, kernel_size=5, act_layer_type='GDN',
+                                                               multiscale_analysis=True), synth.histo_tile(48, 13), 37)
     make_case(ref, 'gdn_canonical_64x64', synth.CANONICAL, synth.histo_tile(64, 4), 17, False, False)
     make_case(ref, 'gdn_canonical_96x80', synth.CANONICAL, rng.integers(0, 256, (96, 80, 3), dtype=np.uint8), 18, False, False)
 

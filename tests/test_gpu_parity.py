@@ -82,7 +82,8 @@ def test_synthesis_matches_reference_golden(cae, name):
 
 
 @pytest.mark.parametrize('name', ['var_bn_gdn_40x56', 'var_bn_lrelu_bias_37x45', 'var_expansion2_gdn_48x48',
-                                  'var_groups_relu_40x40', 'var_groups_k5_32x48'])
+                                  'var_groups_relu_40x40', 'var_groups_k5_32x48', 'var_multiscale_lrelu_bias_40x56',
+                                  'var_multiscale_gdn_k5_48x48'])
 def test_variant_goldens(cae, name):
     """BatchNorm (eval), grouped layers and channel expansion against the reference's own outputs."""
     from test_host import variant_modules
@@ -93,7 +94,11 @@ def test_variant_goldens(cae, name):
     np.testing.assert_allclose(y, g['y'], rtol=RTOL, atol=ATOL)
     x_r, brg = dec.cuda()(torch.round(torch.from_numpy(g['y'])).cuda())
     np.testing.assert_allclose(x_r[0].cpu().numpy(), g['x_r_0'], rtol=RTOL, atol=ATOL)
-    assert all(t is None for t in x_r[1:])
+    for j in range(1, len(x_r)):  # multiscale colour layers, or None as the reference returns
+        if g['x_r_none'][j]:
+            assert x_r[j] is None
+        else:
+            np.testing.assert_allclose(x_r[j].cpu().numpy(), g[f'x_r_{j}'], rtol=RTOL, atol=ATOL)
     assert [tuple(t.shape) for t in brg] == [tuple(g[f'brg_shape_{i}']) for i in range(len(brg))]
     for i, t in enumerate(brg):
         st = np.array([t.double().sum().item(), t.double().abs().sum().item(), (t.double() ** 2).sum().item()])

@@ -212,14 +212,13 @@ def test_unsupported_variants_say_so(cae):
     assert list(a.state_dict()) == [f'analysis_track.{i}.model.{j}.{p}' for i, js in ((0, (0, 2)), (1, (0, 2)), (2, (0,)))
                                     for j in js for p in ('weight', 'bias')]
     assert a.precision_code() == 0  # these variants run on the fp32 kernels
-    with pytest.raises(NotImplementedError):
-        cae.Synthesizer(3, 8, 16, 3, multiscale_analysis=True)
+    assert cae.Synthesizer(3, 8, 16, 3, multiscale_analysis=True).precision_code() == 0  # colour layers: fp32 kernels
     with pytest.raises(NotImplementedError, match='training mode'):  # BatchNorm folds in eval mode only
         cae.Analyzer(3, 8, 16, 3, batch_norm=True).train().analysis_track[0].effective_main()
 
 
 VARIANTS = ['var_bn_gdn_40x56', 'var_bn_lrelu_bias_37x45', 'var_expansion2_gdn_48x48', 'var_groups_relu_40x40',
-            'var_groups_k5_32x48']
+            'var_groups_k5_32x48', 'var_multiscale_lrelu_bias_40x56', 'var_multiscale_gdn_k5_48x48']
 
 
 def variant_modules(cae, g, cfg):
@@ -263,6 +262,13 @@ def test_variant_state_dicts_and_folding_match_the_reference(cae, name):
     x_r, brg = O.synthesis_forward(torch.round(torch.from_numpy(g['y'])), layers(dec.synthesis_track))
     np.testing.assert_allclose(x_r.numpy(), g['x_r_0'], rtol=2e-5, atol=2e-5)
     assert [tuple(t.shape) for t in brg] == [tuple(g[f'brg_shape_{i}']) for i in range(len(brg))]
+    if cfg.get('multiscale_analysis'):  # colour layers: stride-1 reflect convolutions on the intermediate features
+        L, k = cfg['compression_level'], cfg['kernel_size']
+        for i, layer in enumerate(list(dec.color_layers)[:-1]):
+            conv = layer[0]
+            pad = torch.nn.functional.pad(brg[i], (k // 2,) * 4, mode='reflect')
+            ref = torch.nn.functional.conv2d(pad, conv.dense_weight(), None if conv.bias is None else conv.bias.detach())
+            np.testing.assert_allclose(ref.numpy(), g[f'x_r_{L - 1 - i}'], rtol=2e-5, atol=2e-5)
 
 
 def test_checkpoint_schema_round_trip(cae, tmp_path):
