@@ -37,6 +37,8 @@ SYMBOLS = {
     'cae_model_set_entropy': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cae_analysis': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_synthesis': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    'cae_model_set_layer_stage': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_int, c_int]),
     'cae_model_set_color_layer': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_synthesis_multiscale': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                           c_void_p]),

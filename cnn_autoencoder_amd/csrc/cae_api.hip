@@ -260,6 +260,13 @@ int Model::ensure_device() {
     return CAE_OK;
 }
 
+static void free_stages(Layer &l) {
+    for (auto &sg : l.stages)
+        for (float *q : {sg.wp, sg.bias, sg.gp, sg.beta})
+            if (q) (void)hipFree(q);
+    l.stages.clear();
+}
+
 Model::~Model() {
     for (auto *tr : {&enc, &dec})
         for (auto &l : *tr) {
@@ -268,15 +275,14 @@ Model::~Model() {
             if (l.gp) (void)hipFree(l.gp);
             if (l.beta) (void)hipFree(l.beta);
             if (l.wp_edge) (void)hipFree(l.wp_edge);
-            if (l.pre_wp) (void)hipFree(l.pre_wp);
-            if (l.pre_bias) (void)hipFree(l.pre_bias);
+            free_stages(l);
             if (l.color_wp) (void)hipFree(l.color_wp);
             if (l.color_bias) (void)hipFree(l.color_bias);
             if (l.wp16) (void)hipFree(l.wp16);
             if (l.gp16) (void)hipFree(l.gp16);
             if (l.wp_edge16) (void)hipFree(l.wp_edge16);
         }
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 4; ++i)
         if (ws[i]) (void)hipFree(ws[i]);
     for (int i = 0; i < 2; ++i)
         if (ws16[i]) (void)hipFree(ws16[i]);
@@ -328,6 +334,91 @@ static void launch_likelihood(Model *m, const float *y, int n, int hw, float *yh
                               hipStream_t st) {
     hipLaunchKernelGGL(likelihood_kernel<R>, dim3(m->c_bn, n), dim3(256), 0, st, y, m->medians_dev, m->density_dev,
                        m->density_per_channel, m->density_k, m->density_bound, m->c_bn, hw, yhat, lik, part);
+}
+
+// (re)builds stage `stage` of a unit: a stride-1 (transposed) convolution cin -> cin with its epilogue
+static int set_stage(Model *m, int track, Layer &l, int stage, const float *w, const float *bias, const float *beta,
+                     const float *gamma, int act, int add_residual, int post_act) {
+    const int ctin = round_ct(l.cin);
+    if (ctin < 0) return fail(CAE_ERR_UNSUPPORTED, "more than 192 channels not supported");
+    if ((int)l.stages.size() <= stage) l.stages.resize(stage + 1);
+    Layer::Stage &sg = l.stages[stage];
+    // synthesis: ConvTranspose2d(stride 1, padding k//2) == zero-padded correlation with the flipped kernel
+    const bool tr = track == CAE_SYNTHESIS;
+    int rc = upload(pack_weights(w, tr, l.cin, l.cin, m->ks, ctin, tr), &sg.wp);
+    if (rc) return rc;
+    if (bias) {
+        std::vector<float> b(ctin * 32, 0.0f);
+        std::copy(bias, bias + l.cin, b.begin());
+        if ((rc = upload(b, &sg.bias))) return rc;
+    } else if (sg.bias) {
+        (void)hipFree(sg.bias);
+        sg.bias = nullptr;
+    }
+    sg.gdn = beta != nullptr;
+    if (sg.gdn) {
+        std::vector<float> b(ctin * 32, 1.0f);
+        std::copy(beta, beta + l.cin, b.begin());
+        if ((rc = upload(b, &sg.beta))) return rc;
+        if ((rc = upload(pack_gamma(gamma, l.cin, ctin), &sg.gp))) return rc;
+    }
+    sg.act = act;
+    sg.add_res = add_residual != 0;
+    sg.post_act = post_act;
+    if (l.wp_edge && track == CAE_ANALYSIS) {  // the fused first-layer kernel reads the raw tile; a stage sits in between
+        (void)hipFree(l.wp_edge);
+        l.wp_edge = nullptr;
+    }
+    return CAE_OK;
+}
+
+// Runs the stride-1 stages of a unit.  `cur`/`cur_idx`: the unit's input and the workspace slot it lives in; on
+// return they describe the strided layer's input.  Slots 1..3 rotate so that the unit input survives until the
+// residual sum has read it.
+static int pick_slot(int a, int b) {
+    for (int k = 1; k <= 3; ++k)
+        if (k != a && k != b) return k;
+    return 1;
+}
+
+static int run_stages(Model *m, const Layer &l, bool synthesis, int n, int ch, int cw, const float *&cur, int &cur_idx,
+                      int &cur_planes, hipStream_t st) {
+    const float *unit_in = cur;
+    const int unit_idx = cur_idx, unit_planes = cur_planes;
+    for (const Layer::Stage &sg : l.stages) {
+        LayerArgs b{};
+        const int ctin = round_ct(l.cin);
+        const int out_idx = pick_slot(unit_idx, cur_idx);
+        b.in = cur;
+        b.out = m->ws[out_idx];
+        b.wp = sg.wp;
+        b.bias = sg.bias;
+        b.gp = sg.gp;
+        b.beta = sg.beta;
+        b.zero = m->zero;
+        b.N = n;
+        b.H = ch;
+        b.W = cw;
+        b.OH = ch;
+        b.OW = cw;
+        b.in_planes = cur_planes;
+        b.cci = l.chunks;
+        b.out_planes = ctin * 4;
+        b.cout = l.cin;
+        b.tiles_x = (cw + 15) / 16;
+        b.tiles_y = (ch + 2 * CAE_CONV_NW - 1) / (2 * CAE_CONV_NW);
+        b.outfmt = OUT_C8;
+        b.act = sg.act;
+        b.res = sg.add_res ? unit_in : nullptr;
+        b.res_planes = unit_planes;
+        b.post_act = sg.post_act;
+        int rc = launch_conv_s1(m->ks, ctin, synthesis, sg.gdn, b, st);
+        if (rc) return rc;
+        cur = (const float *)b.out;
+        cur_idx = out_idx;
+        cur_planes = ctin * 4;
+    }
+    return CAE_OK;
 }
 
 extern "C" {
@@ -444,34 +535,30 @@ int cae_model_set_layer_act(cae_model_t *mm, int track, int index, int act, cons
         return fail(CAE_ERR_UNSUPPORTED, "LeakyReLU / ReLU units run on the fp32 path: set precision 0");
     if (pre_b && !pre_w) return fail(CAE_ERR_ARG, "pre-convolution bias without weight");
     l.act = act;
-    if (l.pre_wp) {
-        (void)hipFree(l.pre_wp);
-        l.pre_wp = nullptr;
-    }
-    if (l.pre_bias) {
-        (void)hipFree(l.pre_bias);
-        l.pre_bias = nullptr;
-    }
+    free_stages(l);
     if (pre_w) {
-        const int ctin = round_ct(l.cin);
-        if (ctin < 0) return fail(CAE_ERR_UNSUPPORTED, "more than 192 channels not supported");
-        // synthesis: ConvTranspose2d(stride 1, padding k//2) == zero-padded correlation with the flipped kernel
-        const bool tr = track == CAE_SYNTHESIS;
-        int rc = upload(pack_weights(pre_w, tr, l.cin, l.cin, m->ks, ctin, tr), &l.pre_wp);
+        int rc = set_stage(m, track, l, 0, pre_w, pre_b, nullptr, nullptr, act, 0, 0);
         if (rc) return rc;
-        if (pre_b) {
-            std::vector<float> b(ctin * 32, 0.0f);
-            std::copy(pre_b, pre_b + l.cin, b.begin());
-            if ((rc = upload(b, &l.pre_bias))) return rc;
-        }
-        if (l.wp_edge) {  // the fused first-layer kernel reads the raw tile; a pre-convolution sits in between
-            if (track == CAE_ANALYSIS) {
-                (void)hipFree(l.wp_edge);
-                l.wp_edge = nullptr;
-            }
-        }
     }
     return CAE_OK;
+}
+
+int cae_model_set_layer_stage(cae_model_t *mm, int track, int index, int stage, const float *w, const float *bias,
+                              const float *beta, const float *gamma, int act, int add_residual, int post_act) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !w) return fail(CAE_ERR_ARG, "NULL model or weight");
+    if (track != CAE_ANALYSIS && track != CAE_SYNTHESIS) return fail(CAE_ERR_ARG, "bad track %d", track);
+    if (index < 0 || index >= m->L) return fail(CAE_ERR_ARG, "layer index %d out of range", index);
+    if (stage < 0 || stage > 1) return fail(CAE_ERR_ARG, "a unit has at most two stride-1 stages");
+    if (act < 0 || act > 2 || post_act < 0 || post_act > 2) return fail(CAE_ERR_ARG, "bad activation");
+    if ((beta == nullptr) != (gamma == nullptr)) return fail(CAE_ERR_ARG, "beta and gamma must come together");
+    if (beta && act != 0) return fail(CAE_ERR_ARG, "a GDN stage has no other activation");
+    if (m->precision != 0) return fail(CAE_ERR_UNSUPPORTED, "stride-1 stages run on the fp32 path: set precision 0");
+    std::lock_guard<std::mutex> lk(m->mu);
+    Layer &l = (track == CAE_ANALYSIS ? m->enc : m->dec)[index];
+    if (!l.set) return fail(CAE_ERR_ARG, "set the layer before its stages");
+    if (stage > (int)l.stages.size()) return fail(CAE_ERR_ARG, "set stage 0 before stage 1");
+    return set_stage(m, track, l, stage, w, bias, beta, gamma, act, add_residual, post_act);
 }
 
 int cae_model_set_color_layer(cae_model_t *mm, int index, int cin, int cout, const float *w, const float *bias) {
@@ -552,7 +639,7 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
     {
         int ch = h, cw = w;
         for (int i = 0; i < m->L; ++i) {
-            if (m->enc[i].pre_wp)  // stride-1 pre-convolution: same size, cin channels
+            if (!m->enc[i].stages.empty())  // stride-1 stages: same size, cin channels
                 maxact = std::max(maxact, (size_t)n * round_ct(m->enc[i].cin) * 4 * ch * cw * 32);
             ch = (ch + 1) / 2;
             cw = (cw + 1) / 2;
@@ -561,8 +648,11 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
     }
     const bool u8_wide = f16 && !first_fused && fmt == CAE_FMT_U8_HWC;  // staged through fp32 C8 in ws[1]
     if (u8_wide) maxact = std::max(maxact, (size_t)n * p0 * h * w * 32);
+    bool need_third_slot = false;  // two-stage residual units keep the unit input alive across both stages
+    for (auto &l : m->enc) need_third_slot |= l.stages.size() > 1;
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
     if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
+    if (maxact && need_third_slot && (rc = m->ensure_ws(3, maxact))) return rc;
 
     ProfScope prof(m, CAE_ANALYSIS, st);
     prof.begin();
@@ -592,39 +682,15 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
 
     const float *cur = (const float *)m->ws[0];
     int cur_planes = p0, ch = h, cw = w;
-    int flip = 0;  // which of ws[1] / ws[2] receives the next intermediate
+    int cur_idx = 0;  // workspace slot holding `cur` (0 = converted input; 1..3 rotate)
     for (int i = 0; i < m->L; ++i) {
         const Layer &l = m->enc[i];
         const bool last = i == m->L - 1;
-        if (l.pre_wp) {  // Conv2d(cin, cin, k, stride 1, reflect) + activation  (_autoencoders.py:62-76)
-            LayerArgs b{};
-            const int ctin = round_ct(l.cin);
-            b.in = cur;
-            b.out = m->ws[1 + flip];
-            b.wp = l.pre_wp;
-            b.bias = l.pre_bias;
-            b.zero = m->zero;
-            b.N = n;
-            b.H = ch;
-            b.W = cw;
-            b.OH = ch;
-            b.OW = cw;
-            b.in_planes = cur_planes;
-            b.cci = l.chunks;
-            b.out_planes = ctin * 4;
-            b.cout = l.cin;
-            b.tiles_x = (cw + 15) / 16;
-            b.tiles_y = (ch + 2 * CAE_CONV_NW - 1) / (2 * CAE_CONV_NW);
-            b.outfmt = OUT_C8;
-            b.act = l.act;
-            if ((rc = launch_conv_s1(m->ks, ctin, false, b, st))) return rc;
-            cur = (const float *)b.out;
-            cur_planes = ctin * 4;
-            flip ^= 1;
-        }
+        if (!l.stages.empty() && (rc = run_stages(m, l, false, n, ch, cw, cur, cur_idx, cur_planes, st))) return rc;
         LayerArgs a{};
         a.in = cur;
-        a.out = last ? (void *)latents : m->ws[1 + flip];
+        const int out_idx = pick_slot(cur_idx, cur_idx);
+        a.out = last ? (void *)latents : m->ws[out_idx];
         a.act = l.act;
         a.wp = l.wp;
         a.bias = l.bias;
@@ -669,7 +735,7 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
         cur_planes = l.ct * 4;
         ch = a.OH;
         cw = a.OW;
-        flip ^= 1;
+        cur_idx = out_idx;
     }
     return CAE_OK;
 }
@@ -702,15 +768,18 @@ int cae_synthesis_multiscale(cae_model_t *mm, const float *latents, int n, int l
     {
         int ch = lh, cw = lw;
         for (int i = 0; i < m->L; ++i) {
-            if (m->dec[i].pre_wp)
+            if (!m->dec[i].stages.empty())
                 maxact = std::max(maxact, (size_t)n * round_ct(m->dec[i].cin) * 4 * ch * cw * 32);
             ch *= 2;
             cw *= 2;
             if (i + 1 < m->L) maxact = std::max(maxact, (size_t)n * m->dec[i].ct * 4 * ch * row_bytes(cw));
         }
     }
+    bool need_third_slot = false;
+    for (auto &l : m->dec) need_third_slot |= l.stages.size() > 1;
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
     if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
+    if (maxact && need_third_slot && (rc = m->ensure_ws(3, maxact))) return rc;
 
     ProfScope prof(m, CAE_SYNTHESIS, st);
     prof.begin();
@@ -726,39 +795,15 @@ int cae_synthesis_multiscale(cae_model_t *mm, const float *latents, int n, int l
 
     const float *cur = (const float *)m->ws[0];
     int cur_planes = p0, ch = lh, cw = lw;
-    int flip = 0;
+    int cur_idx = 0;
     for (int i = 0; i < m->L; ++i) {
         const Layer &l = m->dec[i];
         const bool last = i == m->L - 1;
-        if (l.pre_wp) {  // ConvTranspose2d(cin, cin, k, stride 1, padding k//2) + activation (_autoencoders.py:187-202)
-            LayerArgs b{};
-            const int ctin = round_ct(l.cin);
-            b.in = cur;
-            b.out = m->ws[1 + flip];
-            b.wp = l.pre_wp;
-            b.bias = l.pre_bias;
-            b.zero = m->zero;
-            b.N = n;
-            b.H = ch;
-            b.W = cw;
-            b.OH = ch;
-            b.OW = cw;
-            b.in_planes = cur_planes;
-            b.cci = l.chunks;
-            b.out_planes = ctin * 4;
-            b.cout = l.cin;
-            b.tiles_x = (cw + 15) / 16;
-            b.tiles_y = (ch + 2 * CAE_CONV_NW - 1) / (2 * CAE_CONV_NW);
-            b.outfmt = OUT_C8;
-            b.act = l.act;
-            if ((rc = launch_conv_s1(m->ks, ctin, true, b, st))) return rc;
-            cur = (const float *)b.out;
-            cur_planes = ctin * 4;
-            flip ^= 1;
-        }
+        if (!l.stages.empty() && (rc = run_stages(m, l, true, n, ch, cw, cur, cur_idx, cur_planes, st))) return rc;
         LayerArgs a{};
         a.in = cur;
-        a.out = last ? out : m->ws[1 + flip];
+        const int out_idx = pick_slot(cur_idx, cur_idx);
+        a.out = last ? out : m->ws[out_idx];
         a.act = l.act;
         a.wp = l.wp;
         a.bias = l.bias;
@@ -824,7 +869,7 @@ int cae_synthesis_multiscale(cae_model_t *mm, const float *latents, int n, int l
             c.tiles_y = (a.OH + 2 * CAE_CONV_NW - 1) / (2 * CAE_CONV_NW);
             c.outfmt = OUT_NCHW;
             c.act = 0;
-            if ((rc = launch_conv_s1(m->ks, round_ct(l.color_cout), false, c, st))) return rc;
+            if ((rc = launch_conv_s1(m->ks, round_ct(l.color_cout), false, false, c, st))) return rc;
         }
         if (!last && bridges && bridges[i]) {
             const size_t t2 = (size_t)n * l.cout * a.OH * a.OW;
@@ -840,7 +885,7 @@ int cae_synthesis_multiscale(cae_model_t *mm, const float *latents, int n, int l
         cur_planes = l.ct * 4;
         ch = a.OH;
         cw = a.OW;
-        flip ^= 1;
+        cur_idx = out_idx;
     }
     return CAE_OK;
 }

@@ -21,8 +21,16 @@ struct Layer {
     float *beta = nullptr;  // [ct*32] (device)
     float *wp_edge = nullptr;  // packed weights of the specialised first-conv / last-deconv kernel, or null
     // LeakyReLU / ReLU units: stride-1 convolution (cin -> cin) + activation in front of the strided one
-    float *pre_wp = nullptr;   // packed weights of the pre-convolution, or null
-    float *pre_bias = nullptr;
+    // stride-1 (transposed) convolutions cin -> cin in front of the strided layer: the pre-convolution of the
+    // LeakyReLU / ReLU units and the res_model of the residual units (_autoencoders.py:62-76, :104-174, :230-304)
+    struct Stage {
+        float *wp = nullptr, *bias = nullptr, *gp = nullptr, *beta = nullptr;
+        bool gdn = false;      // GDN (analysis) / IGDN (synthesis) after the convolution, else `act`
+        int act = 0;
+        bool add_res = false;  // + the unit's input after the activation (residual units)
+        int post_act = 0;      // activation after the residual sum (the strided layer's pre-activation)
+    };
+    std::vector<Stage> stages;
     // multiscale colour layer on this synthesis level's output (stride-1 reflect conv to the image channels), or null
     float *color_wp = nullptr;
     float *color_bias = nullptr;
@@ -67,8 +75,8 @@ struct Model {
     double *bits_ws = nullptr;
     size_t bits_ws_elems = 0;
     float *zero = nullptr;
-    void *ws[3] = {nullptr, nullptr, nullptr};
-    size_t ws_bytes[3] = {0, 0, 0};
+    void *ws[4] = {nullptr, nullptr, nullptr, nullptr};  // converted input + three activation buffers
+    size_t ws_bytes[4] = {0, 0, 0, 0};
     std::mutex mu;
     // profiling: per track, per profiled call, the event pairs of every launched kernel
     int precision = 0;  // 0 = fp32 MFMA, 1 = f16x3 split MFMA

@@ -52,6 +52,9 @@ struct LayerArgs {
     int tiles_x, tiles_y;
     int outfmt;
     int act;            // epilogue activation: 0 none, 1 LeakyReLU(0.01), 2 ReLU (nn.LeakyReLU / nn.ReLU defaults)
+    const float *res;   // C8 tensor [N][res_planes][OH][OW][8] added after `act` (residual units), or nullptr
+    int res_planes;     // planes of `res` (the unit input may carry fewer padded planes than the output)
+    int post_act;       // activation after the residual sum
 };
 
 // compile-time unrolled loop: f(std::integral_constant<int, I>{}) for I = 0..N-1
@@ -188,8 +191,14 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[CT], const 
                     f32x4 v;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = ACT ? apply_act(acc[ct][4 * g + k], p.act) : acc[ct][4 * g + k];
-                    float *dst = out + ((((size_t)n * p.out_planes + plane) * p.OH + oy) * p.OW + ox) * 8 + 4 * h;
-                    *(f32x4 *)dst = v;
+                    const size_t off = ((((size_t)n * p.out_planes + plane) * p.OH + oy) * p.OW + ox) * 8 + 4 * h;
+                    if (ACT) {  // residual units: + unit input, then the strided layer's pre-activation
+                        if (p.res && plane < p.res_planes)
+                            v += *(const f32x4 *)(p.res + ((((size_t)n * p.res_planes + plane) * p.OH + oy) * p.OW + ox) * 8 + 4 * h);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], p.post_act);
+                    }
+                    *(f32x4 *)(out + off) = v;
                 }
             }
     } else if (p.outfmt == OUT_NCHW) {
@@ -221,7 +230,7 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[CT], const 
 template <int CT, bool MAY_ACT = true>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
                                             int h, bool valid) {
-    if (MAY_ACT && p.act != 0)
+    if (MAY_ACT && (p.act != 0 || p.res != nullptr || p.post_act != 0))
         store_tiles_impl<CT, true>(acc, p, n, oy, ox, h, valid);
     else
         store_tiles_impl<CT, false>(acc, p, n, oy, ox, h, valid);
@@ -238,7 +247,7 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const Layer
 #endif
 // S = stride (2: DownsamplingUnit's strided conv; 1: the pre-activation conv of the LeakyReLU/ReLU units,
 // _autoencoders.py:62-70, and -- with ZEROPAD and flipped weights -- ConvTranspose2d(stride 1), :187-196)
-template <int KS, int CT, int NW, bool GDN, int S = 2, bool ZEROPAD = false>
+template <int KS, int CT, int NW, bool GDN, int S = 2, bool ZEROPAD = false, bool INV = false>
 __global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : (CT <= 4 ? CAE_CONV_WAVES : 2)) conv_s2_kernel(const LayerArgs p) {
     constexpr int PAD = KS / 2;
     constexpr int TX = 16, TY = 2 * NW;
@@ -377,7 +386,7 @@ __global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : (CT <= 4 ? CAE
     }
 
     if constexpr (GDN) {
-        gdn_stages<CT, NW, false, STAGE_BYTES>(acc, p, smem, sc, wave, lane, [](char *) {});
+        gdn_stages<CT, NW, INV, STAGE_BYTES>(acc, p, smem, sc, wave, lane, [](char *) {});  // INV: IGDN (synthesis res_model)
     }
 
     const int oy = oy0 + wrow, ox = ox0 + (m & 15);

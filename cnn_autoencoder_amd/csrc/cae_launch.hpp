@@ -20,7 +20,7 @@ namespace cae {
 struct LayerArgs;
 struct FirstArgs;
 int launch_conv(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st);
-int launch_conv_s1(int ks, int ct, bool zeropad, const LayerArgs &a, hipStream_t st);
+int launch_conv_s1(int ks, int ct, bool zeropad, bool gdn, const LayerArgs &a, hipStream_t st);
 int launch_deconv(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st);
 int launch_gdn(int ct, bool inverse, const LayerArgs &a, hipStream_t st);
 int launch_first(int ks, int ct, bool gdn, const LayerArgs &a, const FirstArgs &f, hipStream_t st);

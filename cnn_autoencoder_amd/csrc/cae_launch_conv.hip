@@ -40,13 +40,16 @@ static int launch_conv_t(const LayerArgs &a, hipStream_t st) {
 
 // stride-1 convolutions of the LeakyReLU / ReLU units: reflect padded (analysis) or zero padded with
 // flipped weights (ConvTranspose2d stride 1, synthesis)
-template <int KS, int CT, bool ZP>
+template <int KS, int CT, bool ZP, bool GDN>
 static int launch_conv_s1_t(const LayerArgs &a, hipStream_t st) {
     constexpr int NW = CAE_CONV_NW;
     constexpr int WH = 15 + KS;
     constexpr int HALO_INSTR = (2 * NW * WH * 2 + 63) / 64;
-    constexpr int LDS = 2 * (KS * CT * 1024 + HALO_INSTR * 1024);
-    auto kern = conv_s2_kernel<KS, CT, NW, false, 1, ZP>;
+    constexpr int CONV_STAGE = KS * CT * 1024 + HALO_INSTR * 1024;
+    constexpr int G_BYTES = GDN ? CT * 4096 : 0;
+    constexpr int LDS = 2 * (CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES);
+    // GDN on the analysis track (reflect padded), IGDN on the synthesis track (zero padded, flipped weights)
+    auto kern = conv_s2_kernel<KS, CT, NW, GDN, 1, ZP, GDN && ZP>;
     static bool attr_done = false;
     if (!attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -58,19 +61,21 @@ static int launch_conv_s1_t(const LayerArgs &a, hipStream_t st) {
     return CAE_OK;
 }
 
-int launch_conv_s1(int ks, int ct, bool zeropad, const LayerArgs &a, hipStream_t st) {
-#define S1_CT(KS_, ZP_)                                                          \
+int launch_conv_s1(int ks, int ct, bool zeropad, bool gdn, const LayerArgs &a, hipStream_t st) {
+#define S1_CT(KS_, ZP_, G_)                                                      \
     switch (ct) {                                                                \
-        case 1: return launch_conv_s1_t<KS_, 1, ZP_>(a, st);                     \
-        case 2: return launch_conv_s1_t<KS_, 2, ZP_>(a, st);                     \
-        case 4: return launch_conv_s1_t<KS_, 4, ZP_>(a, st);                     \
-        case 6: return launch_conv_s1_t<KS_, 6, ZP_>(a, st);                     \
+        case 1: return launch_conv_s1_t<KS_, 1, ZP_, G_>(a, st);                 \
+        case 2: return launch_conv_s1_t<KS_, 2, ZP_, G_>(a, st);                 \
+        case 4: return launch_conv_s1_t<KS_, 4, ZP_, G_>(a, st);                 \
+        case 6: return launch_conv_s1_t<KS_, 6, ZP_, G_>(a, st);                 \
         default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct); \
     }
+#define S1_ZP(KS_, G_)                                   \
+    if (zeropad) { S1_CT(KS_, true, G_) } else { S1_CT(KS_, false, G_) }
     if (ks == 3) {
-        if (zeropad) { S1_CT(3, true) } else { S1_CT(3, false) }
+        if (gdn) { S1_ZP(3, true) } else { S1_ZP(3, false) }
     } else if (ks == 5) {
-        if (zeropad) { S1_CT(5, true) } else { S1_CT(5, false) }
+        if (gdn) { S1_ZP(5, true) } else { S1_ZP(5, false) }
     }
     return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
 }

@@ -153,13 +153,11 @@ def _define_act_layer(act_layer_type, channels_in=None, track='analysis'):
 def _check_variant(kernel_size, groups, batch_norm, dropout, use_residual, act_layer_type, channels_expansion):
     if act_layer_type not in (None, 'GDN', 'LeakyReLU', 'ReLU'):
         raise ValueError(f'Activation layer {act_layer_type} not supported')
-    if use_residual:
-        raise NotImplementedError('use_residual units are not built yet')
     if kernel_size not in (3, 5):
         raise NotImplementedError('kernel_size must be 3 or 5')
     if int(channels_expansion) < 1:
         raise ValueError('channels_expansion must be >= 1')
-    del groups, batch_norm, dropout  # grouped / batch-normalised layers are folded on upload; Dropout2d is the identity in eval
+    del groups, batch_norm, dropout, use_residual  # grouped / batch-normalised layers are folded on upload; Dropout2d is the identity in eval
 
 
 def _fold_batch_norm(w: torch.Tensor, b: Optional[torch.Tensor], bn: Optional[nn.BatchNorm2d], transposed: bool):
@@ -246,6 +244,103 @@ class UpsamplingUnit(_Unit):
         super().__init__(channels_in, channels_out, kernel_size, groups, batch_norm, dropout, bias, act_layer_type)
 
 
+class _ResidualUnit(nn.Module):
+    """res_model (stride-1 convolutions on the unit input) + unit input, then model (the strided layer): module
+    order, hence state-dict indices, of the reference's ResidualDownsamplingUnit / ResidualUpsamplingUnit
+    (_autoencoders.py:104-174, :230-304).  On the device the stride-1 convolutions are `stages` of the layer
+    (cae_model_set_layer_stage): y = post_act(act_or_gdn(conv(x)) [+ unit input])."""
+
+    _conv_cls = StridedReflectConv2d
+    _track = 'analysis'
+    _second_stage_act = False  # the synthesis unit activates its second stride-1 convolution, the analysis one not
+
+    def __init__(self, channels_in, channels_out, kernel_size=3, groups=False, batch_norm=False, dropout=0.0,
+                 bias=False, act_layer_type=None):
+        super().__init__()
+        g = channels_in if groups else 1
+        plain_act = act_layer_type is not None and act_layer_type not in ['GDN']
+        res_model = [self._conv_cls(channels_in, channels_in, kernel_size, bias, g)]
+        self._res = [[0, None, None]]  # per stage: [conv index, bn index, gdn index] in res_model
+        if batch_norm:
+            self._res[0][1] = len(res_model)
+            res_model.append(nn.BatchNorm2d(channels_in, affine=True))
+        if act_layer_type == 'GDN':
+            self._res[0][2] = len(res_model)
+        res_model.append(_define_act_layer(act_layer_type, channels_in, track=self._track))
+        if plain_act:
+            self._res.append([len(res_model), None, None])
+            res_model.append(self._conv_cls(channels_in, channels_in, kernel_size, bias, g))
+            if batch_norm:
+                self._res[1][1] = len(res_model)
+                res_model.append(nn.BatchNorm2d(channels_in, affine=True))
+            if self._second_stage_act:
+                res_model.append(_define_act_layer(act_layer_type, channels_in, track=self._track))
+        model = []
+        if plain_act:
+            # (the reference sizes this activation with channels_out; irrelevant for LeakyReLU / ReLU, Appendix B)
+            model.append(_define_act_layer(act_layer_type, channels_out, track=self._track))
+        self.main_index = len(model)
+        model.append(self._conv_cls(channels_in, channels_out, kernel_size, bias, g))
+        self.main_bn_index = self.gdn_index = None
+        if batch_norm:
+            self.main_bn_index = len(model)
+            model.append(nn.BatchNorm2d(channels_out, affine=True))
+        if act_layer_type is not None:
+            if act_layer_type == 'GDN':
+                self.gdn_index = len(model)
+            model.append(_define_act_layer(act_layer_type, channels_out, track=self._track))
+        if dropout > 0.0:
+            model.append(nn.Dropout2d(dropout))
+        self.act_code = _ACT_CODES[act_layer_type]
+        self.res_model = nn.Sequential(*res_model)
+        self.model = nn.Sequential(*model)
+
+    pre = None  # (the stride-1 convolutions are described by stages())
+
+    @property
+    def main(self):
+        return self.model[self.main_index]
+
+    @property
+    def gdn(self):
+        return None if self.gdn_index is None else self.model[self.gdn_index]
+
+    def effective_main(self):
+        conv = self.main
+        bn = None if self.main_bn_index is None else self.model[self.main_bn_index]
+        return _fold_batch_norm(conv.dense_weight(), conv.bias, bn, conv.transposed)
+
+    def stages(self):
+        """[dict(weight, bias, beta, gamma, act, add_residual, post_act)] for cae_model_set_layer_stage."""
+        out = []
+        last = len(self._res) - 1
+        for k, (ci, bi, gi) in enumerate(self._res):
+            conv = self.res_model[ci]
+            w, b = _fold_batch_norm(conv.dense_weight(), conv.bias, None if bi is None else self.res_model[bi],
+                                    conv.transposed)
+            beta = gamma = None
+            if gi is not None:
+                beta, gamma = self.res_model[gi].effective()
+            act = self.act_code if (k == 0 or self._second_stage_act) else 0
+            out.append(dict(weight=w, bias=b, beta=beta, gamma=gamma, act=0 if gi is not None else act,
+                            add_residual=int(k == last), post_act=self.act_code if (k == last and last == 1) else 0))
+        return out
+
+
+class ResidualDownsamplingUnit(_ResidualUnit):
+    pass
+
+
+class ResidualUpsamplingUnit(_ResidualUnit):
+    _conv_cls = StridedConvTranspose2d
+    _track = 'synthesis'
+    _second_stage_act = True
+
+    def __init__(self, channels_in, channels_out, kernel_size=3, groups=False, batch_norm=False, dropout=0.0,
+                 bias=True, act_layer_type=None):
+        super().__init__(channels_in, channels_out, kernel_size, groups, batch_norm, dropout, bias, act_layer_type)
+
+
 class _Track(nn.Module):
     """Shared device plumbing of Analyzer / Synthesizer."""
 
@@ -271,6 +366,8 @@ class _Track(nn.Module):
         prec = getattr(self, 'precision', None) or os.environ.get('CAE_PRECISION', 'f16x3')
         if prec not in ('fp32', 'f16x3'):
             raise ValueError(f"precision must be 'fp32' or 'f16x3', got {prec!r}")
+        if any(isinstance(u, _ResidualUnit) for u in self._units()):
+            return 0  # residual units: stride-1 stages on the fp32 kernels
         if getattr(self, 'multiscale_analysis', False):
             return 0  # colour layers are stride-1 convolutions on the fp32 kernels
         if any(u.act_code for u in self._units()):
@@ -309,7 +406,18 @@ class _Track(nn.Module):
                         self._handle.ptr, self._track_id, i, conv.in_channels, conv.out_channels,
                         w.ctypes.data, None if b is None else b.ctypes.data,
                         None if beta is None else beta.ctypes.data, None if gamma is None else gamma.ctypes.data))
-                    if unit.act_code or unit.pre is not None:
+                    if isinstance(unit, _ResidualUnit):
+                        _lib.check(L.cae_model_set_layer_act(self._handle.ptr, self._track_id, i, unit.act_code, None,
+                                                             None))
+                        for k, sg in enumerate(unit.stages()):
+                            arr = {key: (None if sg[key] is None else
+                                         np.ascontiguousarray(sg[key].detach().float().cpu().numpy()))
+                                   for key in ('weight', 'bias', 'beta', 'gamma')}
+                            ptr = {key: (None if v is None else v.ctypes.data) for key, v in arr.items()}
+                            _lib.check(L.cae_model_set_layer_stage(
+                                self._handle.ptr, self._track_id, i, k, ptr['weight'], ptr['bias'], ptr['beta'],
+                                ptr['gamma'], sg['act'], sg['add_residual'], sg['post_act']))
+                    elif unit.act_code or unit.pre is not None:
                         pw = pb = None
                         if unit.pre is not None:
                             pwt, pbt = unit.effective_pre()
@@ -365,13 +473,14 @@ class Analyzer(_Track):
         if compression_level < 1:
             raise NotImplementedError('compression_level must be >= 1')
         down_track = []
+        DownsamplingUnit_ = ResidualDownsamplingUnit if use_residual else DownsamplingUnit
         prev, curr = channels_org, channels_net
         for _ in range(compression_level - 1):
-            down_track.append(DownsamplingUnit(prev, curr, kernel_size, groups, batch_norm, dropout, bias,
-                                               act_layer_type))
+            down_track.append(DownsamplingUnit_(prev, curr, kernel_size, groups, batch_norm, dropout, bias,
+                                                act_layer_type))
             prev = curr
             curr = prev * channels_expansion  # reference channel plan (_autoencoders.py:330-342)
-        down_track.append(DownsamplingUnit(prev, channels_bn, kernel_size, groups, batch_norm, dropout, bias, None))
+        down_track.append(DownsamplingUnit_(prev, channels_bn, kernel_size, groups, batch_norm, dropout, bias, None))
         self.analysis_track = nn.Sequential(*down_track)
         self.apply(initialize_weights)
         self._setup(channels_org, channels_net, channels_bn, compression_level, kernel_size)
@@ -424,13 +533,14 @@ class Synthesizer(_Track):
         if compression_level < 1:
             raise NotImplementedError('compression_level must be >= 1')
         up_track = []
+        UpsamplingUnit_ = ResidualUpsamplingUnit if use_residual else UpsamplingUnit
         # reference channel plan (_autoencoders.py:385-400): starts at net * e^L and divides by e per level
         prev, curr = channels_bn, channels_net * channels_expansion ** compression_level
         for _ in range(compression_level - 1):
-            up_track.append(UpsamplingUnit(prev, curr, kernel_size, groups, batch_norm, dropout, bias, act_layer_type))
+            up_track.append(UpsamplingUnit_(prev, curr, kernel_size, groups, batch_norm, dropout, bias, act_layer_type))
             prev = curr
             curr = prev // channels_expansion
-        up_track.append(UpsamplingUnit(prev, channels_org, kernel_size, groups, batch_norm, dropout, bias, None))
+        up_track.append(UpsamplingUnit_(prev, channels_org, kernel_size, groups, batch_norm, dropout, bias, None))
         self.synthesis_track = nn.Sequential(*up_track)
         if multiscale_analysis:
             # reference channel plan (_autoencoders.py:417-428): net * e^i, i descending; it matches the track's

@@ -103,6 +103,15 @@ int cae_analysis(cae_model_t *m, const void *tiles_dev, int fmt, int n, int h, i
 int cae_synthesis(cae_model_t *m, const float *latents_dev, int n, int lh, int lw,
                   void *out_dev, int fmt, float *const *bridges_dev, void *stream);
 
+/* Residual units (ResidualDownsamplingUnit / ResidualUpsamplingUnit, _autoencoders.py:104-174, :230-304) and, in
+ * general, the stride-1 (transposed) convolutions cin -> cin in front of a unit's strided layer.  Stage `stage`
+ * (0 or 1) computes  y = post_act( act_or_gdn(conv(x_stage)) [+ unit input] ):  w (cin,cin,k,k) with bias or NULL
+ * (BatchNorm folded by the caller), beta/gamma = effective GDN parameters of that stage or NULL, act / post_act as
+ * in cae_model_set_layer_act.  cae_model_set_layer_act clears the stages of its layer (and creates stage 0 from
+ * its pre-convolution), so call it first.  fp32 path only (precision 0). */
+int cae_model_set_layer_stage(cae_model_t *m, int track, int index, int stage, const float *w, const float *bias,
+                              const float *beta, const float *gamma, int act, int add_residual, int post_act);
+
 /* Multiscale colour layers (Synthesizer(multiscale_analysis=True), _autoencoders.py:417-436): a stride-1 reflect
  * convolution from the output of synthesis level `index` (< compression_level-1) to the image channels.
  * w: (cout, cin, k, k).  cae_synthesis_multiscale additionally writes colors_dev[i] (n, cout, lh*2^(i+1),

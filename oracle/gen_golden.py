@@ -229,6 +229,15 @@ def main():
                       synth.histo_tile(40, 12, 56), 36)
     make_variant_case(ref, 'var_multiscale_gdn_k5_48x48', dict(vk, kernel_size=5, act_layer_type='GDN',
                                                                multiscale_analysis=True), synth.histo_tile(48, 13), 37)
+    # residual units (res_model + unit input, then the strided layer)
+    make_variant_case(ref, 'var_res_gdn_40x56', dict(vk, use_residual=True, act_layer_type='GDN'),
+                      synth.histo_tile(40, 14, 56), 38)
+    make_variant_case(ref, 'var_res_lrelu_bn_bias_37x45', dict(vk, use_residual=True, batch_norm=True, bias=True,
+                                                               act_layer_type='LeakyReLU'),
+                      np.random.default_rng(299).integers(0, 256, (37, 45, 3), dtype=np.uint8), 39)
+    make_variant_case(ref, 'var_res_none_k5_48x48', dict(vk, use_residual=True, kernel_size=5), synth.histo_tile(48, 15), 40)
+    make_variant_case(ref, 'var_res_relu_mid_32x32', dict(vk, use_residual=True, channels_net=40, channels_bn=24,
+                                                          act_layer_type='ReLU'), synth.histo_tile(32, 16), 41)
     make_case(ref, 'gdn_canonical_64x64', synth.CANONICAL, synth.histo_tile(64, 4), 17, False, False)
     make_case(ref, 'gdn_canonical_96x80', synth.CANONICAL, rng.integers(0, 256, (96, 80, 3), dtype=np.uint8), 18, False, False)
 

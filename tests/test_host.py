@@ -200,9 +200,9 @@ def test_init_and_state_dict_keys_match_reference_fixture(cae):
 
 
 def test_unsupported_variants_say_so(cae):
-    for kw in (dict(use_residual=True), dict(kernel_size=7)):
-        with pytest.raises(NotImplementedError):
-            cae.Analyzer(3, 8, 16, 3, **kw)
+    with pytest.raises(NotImplementedError):
+        cae.Analyzer(3, 8, 16, 3, kernel_size=7)
+    assert cae.Analyzer(3, 8, 16, 3, use_residual=True, act_layer_type='GDN').precision_code() == 0  # fp32 kernels
     with pytest.raises(ValueError, match='not supported'):  # the reference's own message (_autoencoders.py:32)
         cae.Analyzer(3, 8, 16, 3, act_layer_type='LeakyRelU')
     with pytest.raises(ValueError, match='divisible by groups'):  # nn.Conv2d's own condition (3 -> 8, groups=3)
@@ -218,7 +218,8 @@ def test_unsupported_variants_say_so(cae):
 
 
 VARIANTS = ['var_bn_gdn_40x56', 'var_bn_lrelu_bias_37x45', 'var_expansion2_gdn_48x48', 'var_groups_relu_40x40',
-            'var_groups_k5_32x48', 'var_multiscale_lrelu_bias_40x56', 'var_multiscale_gdn_k5_48x48']
+            'var_groups_k5_32x48', 'var_multiscale_lrelu_bias_40x56', 'var_multiscale_gdn_k5_48x48',
+            'var_res_gdn_40x56', 'var_res_lrelu_bn_bias_37x45', 'var_res_none_k5_48x48', 'var_res_relu_mid_32x32']
 
 
 def variant_modules(cae, g, cfg):
@@ -235,31 +236,61 @@ def variant_modules(cae, g, cfg):
     return enc.eval(), dec.eval()
 
 
+def cpu_track(units, x, synthesis):
+    """The device's view of a track replayed with torch-CPU ops: per unit the folded stride-1 stages
+    (y = post_act(act_or_gdn(conv(x)) [+ unit input])) and the folded strided layer, exactly the tensors
+    _Track._sync uploads.  -> (output, per-unit outputs)."""
+    F = torch.nn.functional
+
+    def act(v, code):
+        return v if code == 0 else (F.leaky_relu(v, 0.01) if code == 1 else F.relu(v))
+
+    def conv_s1(v, w, b):
+        k = w.shape[-1]
+        if synthesis:
+            return F.conv_transpose2d(v, w, b, stride=1, padding=k // 2)
+        return F.conv2d(F.pad(v, (k // 2,) * 4, mode='reflect'), w, b)
+
+    outs = []
+    for u in units:
+        unit_in = x
+        if hasattr(u, 'stages'):
+            stages = u.stages()
+        elif u.pre is not None:
+            w, b = u.effective_pre()
+            stages = [dict(weight=w, bias=b, beta=None, gamma=None, act=u.act_code, add_residual=0, post_act=0)]
+        else:
+            stages = []
+        for sg in stages:
+            t = conv_s1(x, sg['weight'], sg['bias'])
+            if sg['beta'] is not None:  # effective (re-parametrised) values
+                norm = F.conv2d(t * t, sg['gamma'][:, :, None, None], sg['beta'])
+                t = t * (torch.sqrt(norm) if synthesis else torch.rsqrt(norm))
+            else:
+                t = act(t, sg['act'])
+            if sg['add_residual']:
+                t = t + unit_in
+            x = act(t, sg['post_act'])
+        w, b = u.effective_main()
+        x = O.deconv_s2(x, w, b) if synthesis else O.reflect_conv_s2(x, w, b)
+        if u.gdn is not None:
+            x = O.gdn_forward(x, u.gdn.beta.detach(), u.gdn.gamma.detach(), synthesis, 1e-6)
+        else:
+            x = act(x, u.act_code)
+        outs.append(x)
+    return x, outs
+
+
 @pytest.mark.parametrize('name', VARIANTS)
 def test_variant_state_dicts_and_folding_match_the_reference(cae, name):
     """BatchNorm / groups / channel-expansion variants: the reference's state dict loads strictly, and the folded
     dense layers (what is uploaded to the GPU) reproduce the reference's eval-mode outputs in the CPU oracle."""
     g, cfg = load_golden(name)
     enc, dec = variant_modules(cae, g, cfg)
-    act = cfg['act_layer_type'] if cfg['act_layer_type'] in ('LeakyReLU', 'ReLU') else None
-
-    def layers(track):
-        out = []
-        for u in track:
-            w, b = u.effective_main()
-            d = dict(weight=w, bias=b, beta=None, gamma=None, pre_weight=None, pre_bias=None, act=None)
-            if u.gdn is not None:
-                d['beta'], d['gamma'] = u.gdn.beta.detach(), u.gdn.gamma.detach()
-            if u.pre is not None:
-                d['pre_weight'], d['pre_bias'] = u.effective_pre()
-                d['act'] = act
-            out.append(d)
-        return out
-
     x = O.tile_to_input(g['tile'])
-    y, _ = O.analysis_forward(x, layers(enc.analysis_track))
+    y, _ = cpu_track(enc.analysis_track, x, False)
     np.testing.assert_allclose(y.numpy(), g['y'], rtol=2e-5, atol=2e-5)
-    x_r, brg = O.synthesis_forward(torch.round(torch.from_numpy(g['y'])), layers(dec.synthesis_track))
+    x_r, brg = cpu_track(dec.synthesis_track, torch.round(torch.from_numpy(g['y'])), True)
     np.testing.assert_allclose(x_r.numpy(), g['x_r_0'], rtol=2e-5, atol=2e-5)
     assert [tuple(t.shape) for t in brg] == [tuple(g[f'brg_shape_{i}']) for i in range(len(brg))]
     if cfg.get('multiscale_analysis'):  # colour layers: stride-1 reflect convolutions on the intermediate features
