@@ -42,6 +42,8 @@ SYMBOLS = {
     'cae_model_set_color_layer': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_synthesis_multiscale': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                           c_void_p]),
+    'cae_analysis_symbols': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cae_synthesis_symbols': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'cae_gdn_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_quantize': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'cae_quantize_export': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -244,8 +244,8 @@ int Model::ensure_ws(int which, size_t bytes) {
 
 int Model::ensure_device() {
     if (!zero) {
-        HIP_TRY(hipMalloc((void **)&zero, 256));
-        HIP_TRY(hipMemset(zero, 0, 256));
+        HIP_TRY(hipMalloc((void **)&zero, 1024));  // zero page: out-of-range halo source, null medians (192 floats)
+        HIP_TRY(hipMemset(zero, 0, 1024));
     }
     if (medians_dirty && ent.channels > 0) {
         int rc = upload(ent.medians, &medians_dev);
@@ -396,6 +396,7 @@ static int run_stages(Model *m, const Layer &l, bool synthesis, int n, int ch, i
         b.gp = sg.gp;
         b.beta = sg.beta;
         b.zero = m->zero;
+        b.medians = m->zero;
         b.N = n;
         b.H = ch;
         b.W = cw;
@@ -615,9 +616,23 @@ int cae_model_set_entropy(cae_model_t *mm, int channels, int cdf_stride, const i
     return CAE_OK;
 }
 
+static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int w, void *latents, bool symbols,
+                         void *stream);
+
 int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int w, float *latents, void *stream) {
+    return analysis_impl(mm, tiles, fmt, n, h, w, latents, false, stream);
+}
+
+int cae_analysis_symbols(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int w, int32_t *symbols,
+                         void *stream) {
+    return analysis_impl(mm, tiles, fmt, n, h, w, symbols, true, stream);
+}
+
+static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int w, void *latents, bool symbols,
+                         void *stream) {
     Model *m = reinterpret_cast<Model *>(mm);
     if (!m || !tiles || !latents) return fail(CAE_ERR_ARG, "NULL argument");
+    if (symbols && m->ent.channels == 0) return fail(CAE_ERR_ARG, "entropy model not set");
     if (n < 1 || h < 2 || w < 2) return fail(CAE_ERR_ARG, "bad tile batch %dx%dx%d", n, h, w);
     if (fmt != CAE_FMT_U8_HWC && fmt != CAE_FMT_F32_NCHW) return fail(CAE_ERR_ARG, "bad pixel format %d", fmt);
     for (auto &l : m->enc)
@@ -690,13 +705,14 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
         LayerArgs a{};
         a.in = cur;
         const int out_idx = pick_slot(cur_idx, cur_idx);
-        a.out = last ? (void *)latents : m->ws[out_idx];
+        a.out = last ? latents : m->ws[out_idx];
         a.act = l.act;
         a.wp = l.wp;
         a.bias = l.bias;
         a.gp = l.gp;
         a.beta = l.beta;
         a.zero = m->zero;
+        a.medians = m->zero;
         a.N = n;
         a.H = ch;
         a.W = cw;
@@ -708,7 +724,8 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
         a.cout = l.cout;
         a.tiles_x = (a.OW + 15) / 16;
         a.tiles_y = (a.OH + 2 * CAE_CONV_NW - 1) / (2 * CAE_CONV_NW);
-        a.outfmt = last ? OUT_NCHW : OUT_C8;
+        a.outfmt = last ? (symbols ? OUT_SYM : OUT_NCHW) : OUT_C8;
+        if (last && symbols) a.medians = m->medians_dev;
         prof.begin();
         if (i == 0 && first_fused) {
             FirstArgs f{tiles, fmt == CAE_FMT_U8_HWC ? 1 : 0, l.cin};
@@ -740,15 +757,32 @@ int cae_analysis(cae_model_t *mm, const void *tiles, int fmt, int n, int h, int 
     return CAE_OK;
 }
 
+static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *symbols, int n, int lh, int lw, void *out,
+                          int fmt, float *const *bridges, float *const *colors, void *stream);
+
 int cae_synthesis(cae_model_t *mm, const float *latents, int n, int lh, int lw, void *out, int fmt,
                   float *const *bridges, void *stream) {
-    return cae_synthesis_multiscale(mm, latents, n, lh, lw, out, fmt, bridges, nullptr, stream);
+    if (!latents) return fail(CAE_ERR_ARG, "NULL argument");
+    return synthesis_impl(mm, latents, nullptr, n, lh, lw, out, fmt, bridges, nullptr, stream);
 }
 
 int cae_synthesis_multiscale(cae_model_t *mm, const float *latents, int n, int lh, int lw, void *out, int fmt,
                              float *const *bridges, float *const *colors, void *stream) {
+    if (!latents) return fail(CAE_ERR_ARG, "NULL argument");
+    return synthesis_impl(mm, latents, nullptr, n, lh, lw, out, fmt, bridges, colors, stream);
+}
+
+int cae_synthesis_symbols(cae_model_t *mm, const int32_t *symbols, int n, int lh, int lw, void *out, int fmt,
+                          void *stream) {
+    if (!symbols) return fail(CAE_ERR_ARG, "NULL argument");
+    return synthesis_impl(mm, nullptr, symbols, n, lh, lw, out, fmt, nullptr, nullptr, stream);
+}
+
+static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *symbols, int n, int lh, int lw, void *out,
+                          int fmt, float *const *bridges, float *const *colors, void *stream) {
     Model *m = reinterpret_cast<Model *>(mm);
-    if (!m || !latents || !out) return fail(CAE_ERR_ARG, "NULL argument");
+    if (!m || !out) return fail(CAE_ERR_ARG, "NULL argument");
+    if (symbols && m->ent.channels == 0) return fail(CAE_ERR_ARG, "entropy model not set");
     if (n < 1 || lh < 1 || lw < 1) return fail(CAE_ERR_ARG, "bad latent batch %dx%dx%d", n, lh, lw);
     if (fmt != CAE_FMT_U8_HWC && fmt != CAE_FMT_F32_NCHW) return fail(CAE_ERR_ARG, "bad pixel format %d", fmt);
     for (auto &l : m->dec)
@@ -786,10 +820,10 @@ int cae_synthesis_multiscale(cae_model_t *mm, const float *latents, int n, int l
     const size_t tot = (size_t)n * p0 * lh * lw;
     if (f16)
         hipLaunchKernelGGL(nchw_to_c8s_kernel<true>, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (char *)m->ws[0], n,
-                           m->c_bn, lh, lw, p0);
+                           m->c_bn, lh, lw, p0, symbols, (const float *)m->medians_dev);
     else
         hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (float *)m->ws[0], n,
-                           m->c_bn, lh * lw, p0);
+                           m->c_bn, lh * lw, p0, symbols, (const float *)m->medians_dev);
     HIP_TRY(hipGetLastError());
     prof.end();
 
@@ -810,6 +844,7 @@ int cae_synthesis_multiscale(cae_model_t *mm, const float *latents, int n, int l
         a.gp = l.gp;
         a.beta = l.beta;
         a.zero = m->zero;
+        a.medians = m->zero;
         a.N = n;
         a.H = ch;
         a.W = cw;
@@ -856,6 +891,7 @@ int cae_synthesis_multiscale(cae_model_t *mm, const float *latents, int n, int l
             c.wp = l.color_wp;
             c.bias = l.color_bias;
             c.zero = m->zero;
+            c.medians = m->zero;
             c.N = n;
             c.H = a.OH;
             c.W = a.OW;
@@ -902,6 +938,7 @@ int cae_gdn_forward(cae_model_t *mm, int track, int index, const float *x, int n
     if (!l.set || !l.gdn) return fail(CAE_ERR_ARG, "layer has no GDN");
     const int planes = l.ct * 4;
     int rc;
+    if ((rc = m->ensure_device())) return rc;
     if ((rc = m->ensure_ws(0, (size_t)n * planes * h * w * 32))) return rc;
     const size_t tot = (size_t)n * planes * h * w;
     hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, x, (float *)m->ws[0], n, l.cout, h * w,
@@ -921,6 +958,8 @@ int cae_gdn_forward(cae_model_t *mm, int track, int index, const float *x, int n
     a.out_planes = planes;
     a.cout = l.cout;
     a.outfmt = OUT_NCHW;
+    a.zero = m->zero;
+    a.medians = m->zero;
     return launch_gdn(l.ct, track == CAE_SYNTHESIS, a, st);
 }
 

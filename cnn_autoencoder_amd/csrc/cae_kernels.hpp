@@ -34,7 +34,7 @@ namespace cae {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum OutFmt { OUT_C8 = 0, OUT_NCHW = 1, OUT_U8HWC = 2 };
+enum OutFmt { OUT_C8 = 0, OUT_NCHW = 1, OUT_U8HWC = 2, OUT_SYM = 3 };  // OUT_SYM: NCHW int32 round(v - median_c)
 
 struct LayerArgs {
     const float *in;    // C8 [N][in_planes][H][W][8]
@@ -55,6 +55,7 @@ struct LayerArgs {
     const float *res;   // C8 tensor [N][res_planes][OH][OW][8] added after `act` (residual units), or nullptr
     int res_planes;     // planes of `res` (the unit input may carry fewer padded planes than the output)
     int post_act;       // activation after the residual sum
+    const float *medians;  // >= 192 floats: per-channel medians (OUT_SYM, fused quantiser) or zeros; never null
 };
 
 // compile-time unrolled loop: f(std::integral_constant<int, I>{}) for I = 0..N-1
@@ -201,29 +202,33 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[CT], const 
                     *(f32x4 *)(out + off) = v;
                 }
             }
-    } else if (p.outfmt == OUT_NCHW) {
-        float *out = (float *)p.out;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = 32 * ct + acc_row(r) + 4 * h;
-                if (c < p.cout)
-                    out[(((size_t)n * p.cout + c) * p.OH + oy) * p.OW + ox] = ACT ? apply_act(acc[ct][r], p.act) : acc[ct][r];
-            }
-    } else {  // OUT_U8HWC: x*255 -> clip(0,255) -> truncating cast  (_autoencoders.py:576-580)
-        uint8_t *out = (uint8_t *)p.out;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+    } else {
+        // NCHW float | NCHW int32 symbols (fused quantiser) | HWC uint8.  static_for, not `#pragma unroll`: with
+        // three 16*CT-element loops in one function the unroller gave up on some of them, the accumulators were then
+        // indexed dynamically and lived in scratch memory (3x slower last analysis layer).
+        const int fmt = p.outfmt;
+        static_for<CT>([&](auto ct_tag) __attribute__((always_inline)) {
+            constexpr int ct = decltype(ct_tag)::value;
+            static_for<16>([&](auto r_tag) __attribute__((always_inline)) {
+                constexpr int r = decltype(r_tag)::value;
                 const int c = 32 * ct + acc_row(r) + 4 * h;
                 if (c < p.cout) {
-                    float v = (ACT ? apply_act(acc[ct][r], p.act) : acc[ct][r]) * 255.0f;
-                    v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
-                    out[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + c] = (uint8_t)v;
+                    const float v = ACT ? apply_act(acc[ct][r], p.act) : acc[ct][r];
+                    if (fmt == OUT_U8HWC) {  // x*255 -> clip(0,255) -> truncating cast  (_autoencoders.py:576-580)
+                        float q = v * 255.0f;
+                        q = q < 0.0f ? 0.0f : (q > 255.0f ? 255.0f : q);
+                        ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + c] = (uint8_t)q;
+                    } else {
+                        // OUT_SYM: symbols = int(round_half_even(y - median_c)), stored through the same float store
+                        // (bit pattern); p.medians points at zeros for OUT_NCHW (never null), so both formats share one code path.
+                        // (A separate int32 store path made the compiler keep the accumulators in scratch memory.)
+                        const size_t off = (((size_t)n * p.cout + c) * p.OH + oy) * p.OW + ox;
+                        const float d = v - p.medians[c];
+                        ((float *)p.out)[off] = fmt == OUT_SYM ? __int_as_float((int)rintf(d)) : d;
+                    }
                 }
-            }
+            });
+        });
     }
 }
 
@@ -830,7 +835,9 @@ static __global__ void u8hwc_to_c8_kernel(const uint8_t *in, float *out, int N, 
     }
 }
 
-static __global__ void nchw_to_c8_kernel(const float *in, float *out, int N, int C, int HW, int planes) {
+// (sym != nullptr: fused dequantiser, value = float(sym) + median_c instead of in[])
+static __global__ void nchw_to_c8_kernel(const float *in, float *out, int N, int C, int HW, int planes,
+                                         const int32_t *sym = nullptr, const float *medians = nullptr) {
     const size_t total = (size_t)N * planes * HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
@@ -841,8 +848,13 @@ static __global__ void nchw_to_c8_kernel(const float *in, float *out, int N, int
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c0 = plane * 8 + k, c1 = c0 + 4;
-            lo[k] = c0 < C ? in[(n * C + c0) * HW + pix] : 0.0f;
-            hi[k] = c1 < C ? in[(n * C + c1) * HW + pix] : 0.0f;
+            if (sym) {
+                lo[k] = c0 < C ? (float)sym[(n * C + c0) * HW + pix] + medians[c0] : 0.0f;
+                hi[k] = c1 < C ? (float)sym[(n * C + c1) * HW + pix] + medians[c1] : 0.0f;
+            } else {
+                lo[k] = c0 < C ? in[(n * C + c0) * HW + pix] : 0.0f;
+                hi[k] = c1 < C ? in[(n * C + c1) * HW + pix] : 0.0f;
+            }
         }
         float *dst = out + i * 8;
         *(f32x4 *)dst = lo;

@@ -830,7 +830,8 @@ __global__ void __launch_bounds__(NW * 64, 1) deconv_last_f16_kernel(const Layer
 
 // fp32 NCHW -> split rows (module boundary / latents into the synthesis track); SP: C8SP rows, else C8S
 template <bool SP>
-__global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int H, int W, int planes) {
+__global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int H, int W, int planes,
+                                   const int32_t *sym = nullptr, const float *medians = nullptr) {
     const size_t HW = (size_t)H * W, total = (size_t)N * planes * HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
@@ -841,7 +842,8 @@ __global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int c = plane * 8 + k;
-            const float v = c < C ? in[(n * C + c) * HW + pix] : 0.0f;
+            // sym != nullptr: fused dequantiser (float(sym) + median_c)
+            const float v = c < C ? (sym ? (float)sym[(n * C + c) * HW + pix] + medians[c] : in[(n * C + c) * HW + pix]) : 0.0f;
             _Float16 a, b;
             split_f16(v, a, b);
             vh[k] = a;

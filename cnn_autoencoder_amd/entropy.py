@@ -272,21 +272,29 @@ class EntropyBottleneck(nn.Module):
     def _sync_handle(self) -> _lib.Handle:
         if self._quantized_cdf.numel() == 0:
             raise ValueError('Uninitialized CDFs. Run update() first')
-        ver = (self._quantized_cdf._version, self.quantiles._version, self._quantized_cdf.data_ptr())
+        ver = self.tables_version()
         if self._handle is None:
             self._handle = _lib.Handle(1, 1, self.channels, 1, 3)
         if self._tables_version != ver:
-            cdf = np.ascontiguousarray(self._quantized_cdf.detach().cpu().numpy(), dtype=np.int32)
-            if cdf.ndim != 2 or cdf.shape[0] != self.channels:
-                raise ValueError(f'Invalid CDF size {tuple(cdf.shape)}')
-            lens = np.ascontiguousarray(self._cdf_length.detach().cpu().numpy().reshape(-1), dtype=np.int32)
-            offs = np.ascontiguousarray(self._offset.detach().cpu().numpy().reshape(-1), dtype=np.int32)
-            med = np.ascontiguousarray(self._get_medians().detach().cpu().numpy().reshape(-1), dtype=np.float32)
-            _lib.check(_lib.lib().cae_model_set_entropy(self._handle.ptr, self.channels, cdf.shape[1],
-                                                        cdf.ctypes.data, lens.ctypes.data, offs.ctypes.data,
-                                                        med.ctypes.data))
+            self.upload_tables(self._handle)
             self._tables_version = ver
         return self._handle
+
+    def tables_version(self):
+        return (self._quantized_cdf._version, self.quantiles._version, self._quantized_cdf.data_ptr())
+
+    def upload_tables(self, handle: _lib.Handle) -> None:
+        """cae_model_set_entropy on `handle` (this module's own, or a track's for the fused quantiser)."""
+        if self._quantized_cdf.numel() == 0:
+            raise ValueError('Uninitialized CDFs. Run update() first')
+        cdf = np.ascontiguousarray(self._quantized_cdf.detach().cpu().numpy(), dtype=np.int32)
+        if cdf.ndim != 2 or cdf.shape[0] != self.channels:
+            raise ValueError(f'Invalid CDF size {tuple(cdf.shape)}')
+        lens = np.ascontiguousarray(self._cdf_length.detach().cpu().numpy().reshape(-1), dtype=np.int32)
+        offs = np.ascontiguousarray(self._offset.detach().cpu().numpy().reshape(-1), dtype=np.int32)
+        med = np.ascontiguousarray(self._get_medians().detach().cpu().numpy().reshape(-1), dtype=np.float32)
+        _lib.check(_lib.lib().cae_model_set_entropy(handle.ptr, self.channels, cdf.shape[1], cdf.ctypes.data,
+                                                    lens.ctypes.data, offs.ctypes.data, med.ctypes.data))
 
     @torch.no_grad()
     def quantize_symbols(self, x: torch.Tensor) -> torch.Tensor:

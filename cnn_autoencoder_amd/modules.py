@@ -439,6 +439,15 @@ class _Track(nn.Module):
             self._versions = ver
         return self._handle
 
+    def _sync_entropy(self, eb) -> _lib.Handle:
+        """This track's handle with `eb`'s medians loaded (fused quantiser / dequantiser entry points)."""
+        hd = self._sync()
+        ver = (id(eb), eb.tables_version())
+        if getattr(self, '_entropy_version', None) != ver:
+            eb.upload_tables(hd)
+            self._entropy_version = ver
+        return hd
+
     def set_profiling(self, enable: bool):
         """Bracket every kernel of this track with HIP events (see cae_model_set_profiling)."""
         _lib.check(_lib.lib().cae_model_set_profiling(self._sync().ptr, int(bool(enable))))
@@ -513,6 +522,25 @@ class Analyzer(_Track):
             raise ValueError(f'expected uint8 (B,H,W,{self._dims[0]}), got {tiles.dtype} {tuple(tiles.shape)}')
         tiles = tiles.to(dev).contiguous()
         return self._run(tiles.data_ptr(), _lib.FMT_U8_HWC, tiles.size(0), tiles.size(1), tiles.size(2))
+
+
+    def forward_u8_symbols(self, tiles: torch.Tensor, eb) -> torch.Tensor:
+        """tiles (B,H,W,C) uint8 on the GPU -> int32 symbols round(y - median) of `eb` (an EntropyBottleneck):
+        analysis with the quantiser fused into the last layer's epilogue (cae_analysis_symbols); equals
+        eb.quantize_symbols(self.forward_u8(tiles))."""
+        dev = _lib.require_gpu()
+        if tiles.dim() != 4 or tiles.size(3) != self._dims[0] or tiles.dtype != torch.uint8:
+            raise ValueError(f'expected uint8 (B,H,W,{self._dims[0]}), got {tiles.dtype} {tuple(tiles.shape)}')
+        if eb.channels != self._dims[2]:
+            raise ValueError(f'entropy model has {eb.channels} channels, the latents {self._dims[2]}')
+        tiles = tiles.to(dev).contiguous()
+        hd = self._sync_entropy(eb)
+        n, h, w = tiles.size(0), tiles.size(1), tiles.size(2)
+        lh, lw = self.latent_size(h, w)
+        sym = torch.empty((n, self._dims[2], lh, lw), dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().cae_analysis_symbols(hd.ptr, tiles.data_ptr(), _lib.FMT_U8_HWC, n, h, w, sym.data_ptr(),
+                                                   _lib.stream_ptr()))
+        return sym
 
 
 class NoneColorLayer(nn.Module):
@@ -595,4 +623,22 @@ class Synthesizer(_Track):
     def forward_u8(self, x: torch.Tensor) -> torch.Tensor:
         """y_q -> (B,H,W,C) uint8 tiles; fuses the *255 / clip / truncate / HWC epilogue of codec.decode."""
         out, _, _ = self._run(x, _lib.FMT_U8_HWC, False)
+        return out
+
+    def forward_symbols_u8(self, sym: torch.Tensor, eb) -> torch.Tensor:
+        """int32 symbols (B,channels_bn,h,w) on the GPU -> (B,H,W,C) uint8 tiles: the dequantiser of `eb` fused into
+        the layout conversion in front of the first layer (cae_synthesis_symbols); equals
+        self.forward_u8(eb.dequantize_symbols(sym))."""
+        dev = _lib.require_gpu()
+        if sym.dim() != 4 or sym.size(1) != self._dims[2] or sym.dtype != torch.int32:
+            raise ValueError(f'expected int32 (B,{self._dims[2]},h,w), got {sym.dtype} {tuple(sym.shape)}')
+        if eb.channels != self._dims[2]:
+            raise ValueError(f'entropy model has {eb.channels} channels, the latents {self._dims[2]}')
+        sym = sym.to(dev).contiguous()
+        hd = self._sync_entropy(eb)
+        n, _, lh, lw = sym.shape
+        L = self._dims[3]
+        out = torch.empty((n, lh * 2 ** L, lw * 2 ** L, self._dims[0]), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().cae_synthesis_symbols(hd.ptr, sym.data_ptr(), n, lh, lw, out.data_ptr(), _lib.FMT_U8_HWC,
+                                                    _lib.stream_ptr()))
         return out

@@ -161,8 +161,7 @@ class SlideCoder:
 
         def stage_a(k):
             t = batches[k]
-            y = self.enc.forward_u8(t)
-            sym = self.eb.quantize_symbols(y)
+            sym = self.enc.forward_u8_symbols(t, self.eb)  # quantiser fused into the last layer's epilogue
             n, C = sym.size(0), sym.size(1)
             hw = sym.numel() // (n * C)
             pin = self._pin(('a', k % 3), (n, C, hw), torch.int32)
@@ -197,8 +196,8 @@ class SlideCoder:
             main.wait_event(up)
             sym.record_stream(main)
             lh, lw = h // 2 ** self.level, w // 2 ** self.level
-            y_q = self.eb.dequantize_symbols(sym.reshape(n, self.eb.channels, lh, lw))
-            rec = self.dec.forward_u8(y_q)
+            # dequantiser fused into the layout conversion in front of the first synthesis layer
+            rec = self.dec.forward_symbols_u8(sym.reshape(n, self.eb.channels, lh, lw), self.eb)
             sse = self.tile_sse(rec, t)
             return sse, [len(p) + 16 for p in payloads], h * w * c
 

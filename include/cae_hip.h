@@ -121,6 +121,15 @@ int cae_model_set_color_layer(cae_model_t *m, int index, int cin, int cout, cons
 int cae_synthesis_multiscale(cae_model_t *m, const float *latents_dev, int n, int lh, int lw, void *out_dev, int fmt,
                              float *const *bridges_dev, float *const *colors_dev, void *stream);
 
+/* Fused forms of the codec path (encode: _autoencoders.py:542-551, decode: :568-580): the quantiser runs in the
+ * epilogue of the last analysis layer (symbols (n, channels_bn, lh, lw) int32 instead of float latents) and the
+ * dequantiser in the layout conversion in front of the first synthesis layer.  Same results as
+ * cae_analysis + cae_quantize / cae_dequantize + cae_synthesis; the handle needs cae_model_set_entropy (medians). */
+int cae_analysis_symbols(cae_model_t *m, const void *tiles_dev, int fmt, int n, int h, int w, int32_t *symbols_dev,
+                         void *stream);
+int cae_synthesis_symbols(cae_model_t *m, const int32_t *symbols_dev, int n, int lh, int lw, void *out_dev, int fmt,
+                          void *stream);
+
 /* One GDN / IGDN layer on an NCHW tensor (compressai.layers.GDN.forward; reference call site
  * _autoencoders.py:29-30).  Uses the beta/gamma of layer `index` of `track`. */
 int cae_gdn_forward(cae_model_t *m, int track, int index, const float *x_dev, int n, int h, int w,

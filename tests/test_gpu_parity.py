@@ -316,6 +316,23 @@ def test_error_behaviour(cae):
         model['fact_ent'].module.decompress([b'\x00\x01'], (4, 4))  # truncated stream
 
 
+def test_fused_quantiser_entry_points_equal_the_unfused_path(cae):
+    """cae_analysis_symbols / cae_synthesis_symbols == analysis + quantise / dequantise + synthesis, bit for bit
+    (ragged tile size, medians away from zero)."""
+    from cnn_autoencoder_amd import synth
+    state = synth.synthetic_state(dict(synth.CANONICAL, channels_net=32, channels_bn=48), seed=4)
+    model = cae.autoencoder_from_state_dict(state)
+    enc, dec, eb = (model[k].module for k in ('encoder', 'decoder', 'fact_ent'))
+    with torch.no_grad():
+        eb.quantiles[:, 0, 1] += torch.linspace(-0.4, 0.4, 48, device=eb.quantiles.device)
+    eb.update(force=True)
+    tiles = torch.from_numpy(synth.uniform_tiles(3, 80, 112)).cuda()
+    sym = enc.forward_u8_symbols(tiles, eb)
+    assert torch.equal(sym, eb.quantize_symbols(enc.forward_u8(tiles)))
+    rec = dec.forward_symbols_u8(sym, eb)
+    assert torch.equal(rec, dec.forward_u8(eb.dequantize_symbols(sym)))
+
+
 def test_tile_sse_exact(cae):
     from cnn_autoencoder_amd import slide, synth
     rng = np.random.default_rng(0)
