@@ -90,7 +90,7 @@ class SlideCoder:
         self.eb = _module(codec._model['fact_ent'])
         self.level = len(self.dec.synthesis_track)
         self.coder_threads = coder_threads
-        self.export_blocks = 32  # workgroups of the PCIe export kernel (cae_quantize_export)
+        self.depth = 3  # batches the analysis runs ahead of the synthesis in run()
         self._pinned = {}
         self._copy_stream = None
         self.timers = {}
@@ -156,15 +156,25 @@ class SlideCoder:
             self._copy_stream = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
         copy, copy_up = self._copy_stream
         K = len(batches)
+        # analysis runs DEPTH batches ahead of synthesis: the host always has a batch to code, and the GPU has analysis
+        # work while the first batch crosses the host (D2H + encode + decode + H2D ~ 1.8 steps)
+        DEPTH = self.depth
         tm = dict(host_encode=0.0, host_decode=0.0, wait_host=0.0)
         all_payloads, stats_parts = [], []
+        # all pinned symbol buffers up front (hipHostMalloc of 100 MB costs ~10 ms: not inside the pipeline)
+        n0, h0, w0, _ = batches[0].shape
+        lh0, lw0 = self.enc.latent_size(h0, w0)
+        for j in range(DEPTH + 1):
+            self._pin(('a', j), (n0, self.eb.channels, lh0 * lw0), torch.int32)
+        for j in range(DEPTH + 2):
+            self._pin(('d', j), (n0, self.eb.channels, lh0 * lw0), torch.int32)
 
         def stage_a(k):
             t = batches[k]
             sym = self.enc.forward_u8_symbols(t, self.eb)  # quantiser fused into the last layer's epilogue
             n, C = sym.size(0), sym.size(1)
             hw = sym.numel() // (n * C)
-            pin = self._pin(('a', k % 3), (n, C, hw), torch.int32)
+            pin = self._pin(('a', k % (DEPTH + 1)), (n, C, hw), torch.int32)  # in use until encode(k) is done
             ready = torch.cuda.Event()
             ready.record(main)
             return k, pin, ready, hw, sym
@@ -182,7 +192,9 @@ class SlideCoder:
         def host_decode(enc_future):
             k, payloads, hw, shape, te = enc_future.result()
             t1 = time.perf_counter()
-            back = self._pin(('d', k % 3), shape, torch.int32)  # decode straight into pinned memory
+            # decode straight into pinned memory; the set is free again once H2D(k) has run (DEPTH + 2 sets: the decode
+            # worker may be DEPTH batches ahead of the synthesis whose H2D is still queued)
+            back = self._pin(('d', k % (DEPTH + 2)), shape, torch.int32)
             self.eb.decode_symbols(payloads, hw, self.coder_threads, out=back.numpy())
             return payloads, back, te, time.perf_counter() - t1
 
@@ -202,7 +214,6 @@ class SlideCoder:
             return sse, [len(p) + 16 for p in payloads], h * w * c
 
         pending = []  # (sse tensor on GPU, nbytes list, samples)
-        DEPTH = 2  # analysis runs DEPTH batches ahead of synthesis: the host always has a batch to code
         # two host workers: batch k+1 is range-encoded while batch k is decoded
         with ThreadPoolExecutor(max_workers=1) as enc_pool, ThreadPoolExecutor(max_workers=1) as dec_pool:
             futs = {}
