@@ -251,9 +251,14 @@ __global__ void __launch_bounds__(256, 1) conv_s2_f16_kernel(const LayerArgs p) 
         static_for<KS>([&](auto ky_tag) {
             constexpr int ky = decltype(ky_tag)::value;
             wait_vm0();
+#ifndef CAE_EXP_F16C_NOBAR  // timing-only ablations of this loop (wrong results): profiles/r01_experiments.md
             __syncthreads();
+#endif
             char *cur = smem + (sc & 1) * STAGE_BYTES;
             char *nxt = smem + ((sc + 1) & 1) * STAGE_BYTES;
+            // the whole next stage is issued here, at the top: spreading the LDS-DMA instructions between the MFMA
+            // groups was measured 8-11 % slower (the data simply lands later), profiles/r01_experiments.md
+#ifndef CAE_EXP_F16C_NODMA
             if constexpr (ky + 1 < KS) {
                 issue_stage(q, std::integral_constant<int, ky + 1>{}, nxt);
             } else {
@@ -263,20 +268,26 @@ __global__ void __launch_bounds__(256, 1) conv_s2_f16_kernel(const LayerArgs p) 
                     issue_gamma0<CT, NW>(p, nxt, wave, lane);
                 }
             }
+#endif
             const char *wb = cur + lane * 16;
             const char *hb = cur + b_off;
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
+#ifdef CAE_EXP_F16C_ONETAP
+                constexpr int kxr = 0;  // every tap re-uses tap 0's operands: one third of the LDS reads
+#else
+                const int kxr = kx;
+#endif
                 f16x8 bh[PT], bl[PT];
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) {
-                    bh[pt] = *(const f16x8 *)(hb + pt * B_PT + kx * 16);
-                    bl[pt] = *(const f16x8 *)(hb + pt * B_PT + kx * 16 + B_HL);
+                    bh[pt] = *(const f16x8 *)(hb + pt * B_PT + kxr * 16);
+                    bl[pt] = *(const f16x8 *)(hb + pt * B_PT + kxr * 16 + B_HL);
                 }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const f16x8 ah = *(const f16x8 *)(wb + ((kx * CT + ct) * 2 + 0) * 1024);
-                    const f16x8 al = *(const f16x8 *)(wb + ((kx * CT + ct) * 2 + 1) * 1024);
+                    const f16x8 ah = *(const f16x8 *)(wb + ((kxr * CT + ct) * 2 + 0) * 1024);
+                    const f16x8 al = *(const f16x8 *)(wb + ((kxr * CT + ct) * 2 + 1) * 1024);
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) acc[pt][ct] = mfma3(ah, al, bh[pt], bl[pt], acc[pt][ct]);
                 }
