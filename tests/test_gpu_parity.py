@@ -304,6 +304,31 @@ def test_full_size_properties(cae):
                                rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('ks,shape', [(3, (3, 1000, 1016)), (5, (2, 520, 488)), (3, (1, 2048, 1040))])
+def test_arithmetic_paths_agree_on_large_ragged_tiles(cae, ks, shape):
+    """Sizes the CPU oracle cannot reach in seconds: the exact-fp32 kernels and the f16x3 kernels (different tiling,
+    different row layouts, persistent first / last layers) must agree with each other on ragged, non-power-of-two
+    tiles of the canonical channel counts (k=3 and k=5)."""
+    from cnn_autoencoder_amd import synth
+    cfg = dict(synth.CANONICAL, kernel_size=ks)
+    state = synth.synthetic_state(cfg, seed=5)
+    models = {}
+    for prec in ('fp32', 'f16x3'):
+        m = cae.autoencoder_from_state_dict(state)
+        for k in ('encoder', 'decoder'):
+            m[k].module.precision = prec
+        models[prec] = m
+    n, h, w = shape
+    tiles = torch.from_numpy(synth.uniform_tiles(n, h, w)).cuda()
+    y = {p: m['encoder'].module.forward_u8(tiles) for p, m in models.items()}
+    assert y['fp32'].shape == (n, 192, -(-h // 16), -(-w // 16))
+    np.testing.assert_allclose(y['f16x3'].cpu().numpy(), y['fp32'].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    yq = torch.round(y['fp32'])
+    rec = {p: m['decoder'].module.forward_u8(yq) for p, m in models.items()}
+    diff = (rec['fp32'].int() - rec['f16x3'].int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3
+
+
 def test_error_behaviour(cae):
     from cnn_autoencoder_amd import synth
     state = synth.synthetic_state(dict(synth.CANONICAL, channels_net=32, channels_bn=48), seed=2)
