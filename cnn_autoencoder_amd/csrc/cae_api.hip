@@ -422,6 +422,15 @@ static int run_stages(Model *m, const Layer &l, bool synthesis, int n, int ch, i
     return CAE_OK;
 }
 
+// LDS need of conv_s2_f16_kernel<KS,CT,GDN> (same formula as the kernel's constexprs): two stage buffers of
+// weights + halo.  k=5 with 192 output channels needs 192 KiB: such a layer runs on the fp32 kernel instead.
+static bool conv_f16_fits(int ks, int ct, bool gdn) {
+    if (gdn && ct > 4) return false;
+    const int halo_instr = (4 * 16 * (2 * 16 + ks - 2) + 63) / 64;
+    const int stage = std::max(ks * ct * 2048 + halo_instr * 1024, gdn ? ct * 4096 : 0);
+    return 2 * stage <= 160 * 1024;
+}
+
 extern "C" {
 
 int cae_version(void) { return 1; }
@@ -664,7 +673,7 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
     const bool u8_wide = f16 && !first_fused && fmt == CAE_FMT_U8_HWC;  // staged through fp32 C8 in ws[1]
     if (u8_wide) maxact = std::max(maxact, (size_t)n * p0 * h * w * 32);
     bool need_third_slot = false;  // two-stage residual units keep the unit input alive across both stages
-    for (auto &l : m->enc) need_third_slot |= l.stages.size() > 1;
+    for (auto &l : m->enc) need_third_slot |= l.stages.size() > 1 || (f16 && !conv_f16_fits(m->ks, l.ct, l.gdn));
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
     if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
     if (maxact && need_third_slot && (rc = m->ensure_ws(3, maxact))) return rc;
@@ -738,12 +747,30 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
                 a.wp = l.wp_edge;
                 if ((rc = launch_first(m->ks, l.ct, l.gdn, a, f, st))) return rc;
             }
-        } else if (f16) {
+        } else if (f16 && conv_f16_fits(m->ks, l.ct, l.gdn)) {
             a.wp = (const float *)l.wp16;
             a.gp = (const float *)l.gp16;
             a.cci = (l.cin + 15) / 16;
             a.tiles_y = (a.OH + 15) / 16;
             if ((rc = launch_conv_f16(m->ks, l.ct, l.gdn, a, st))) return rc;
+        } else if (f16) {
+            // this layer on the exact-fp32 kernel: split rows -> fp32 C8, convolution, (fp32 C8 -> split rows)
+            const int tmp_in = pick_slot(cur_idx, out_idx);
+            const size_t rows = (size_t)n * cur_planes * ch;
+            hipLaunchKernelGGL(c8s_to_c8_kernel, dim3(ew_grid(rows * cw)), dim3(256), 0, st, (const char *)cur,
+                               (float *)m->ws[tmp_in], rows, cw);
+            HIP_TRY(hipGetLastError());
+            a.in = (const float *)m->ws[tmp_in];
+            void *final_out = a.out;
+            if (!last) a.out = m->ws[cur_idx == 0 ? pick_slot(tmp_in, out_idx) : cur_idx];  // the input slot is free now
+            if ((rc = launch_conv(m->ks, l.ct, l.gdn, a, st))) return rc;
+            if (!last) {
+                const size_t orows = (size_t)n * l.ct * 4 * a.OH;
+                hipLaunchKernelGGL(c8_to_c8s_kernel, dim3(ew_grid(orows * a.OW)), dim3(256), 0, st, (const float *)a.out,
+                                   (char *)final_out, orows, a.OW);
+                HIP_TRY(hipGetLastError());
+                a.out = final_out;
+            }
         } else {
             if ((rc = launch_conv(m->ks, l.ct, l.gdn, a, st))) return rc;
         }

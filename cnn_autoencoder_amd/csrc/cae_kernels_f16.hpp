@@ -903,4 +903,21 @@ static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t rows,
     }
 }
 
+// C8S rows -> fp32 C8 [rows][W][8] (a layer the f16x3 kernels do not cover runs on the fp32 kernel)
+static __global__ void c8s_to_c8_kernel(const char *in, float *out, size_t rows, int W) {
+    const size_t npix = rows * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const char *src = in + (i / W) * c8s_row_bytes<false>(W) + c8s_piece<false>((int)(i % W));
+        const f16x8 vh = *(const f16x8 *)src, vl = *(const f16x8 *)(src + 512);
+        f32x4 a, b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = (float)vh[k] + (float)vl[k];
+            b[k] = (float)vh[4 + k] + (float)vl[4 + k];
+        }
+        *(f32x4 *)(out + i * 8) = a;
+        *(f32x4 *)(out + i * 8 + 4) = b;
+    }
+}
+
 }  // namespace cae

@@ -374,9 +374,6 @@ class _Track(nn.Module):
             return 0  # LeakyReLU / ReLU units (stride-1 pre-convolutions) are built on the fp32 kernels
         if any(u.gdn is not None and u.main.out_channels > 128 for u in self._units()):
             return 0  # the f16x3 GDN epilogue covers up to 128 channels
-        if self._track_id == _lib.CAE_ANALYSIS and self._dims[4] == 5 and any(
-                u.main.out_channels > 128 for u in self._units()):
-            return 0  # k=5 with more than 128 output channels: the f16x3 conv stage (weights + halo) exceeds the LDS
         return 1 if prec == 'f16x3' else 0
 
     def _units(self):
