@@ -352,9 +352,10 @@ __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gb
 //   K = (tap, 4 channels): k-step s, lane half h covers taps 4s+2h, 4s+2h+1 (two float4 halo reads).
 //   packed weights: [s][ct][hl][lane][8]: W(cout, tap = 4s + 2(lane>>5) + (j>>2), ch = j&3)
 //   PERSISTENT: one block of 8 waves per CU walks over 16x16-pixel output tiles; the packed weights, the
-//   whole packed gamma, bias/beta and the /255 table stay in LDS, the next tile's input pixels are fetched
-//   into registers under the current tile's MFMAs.  (The one-tile-per-block form re-read 120 KB of weights
-//   and gamma per 128 output pixels and exposed its whole prologue: 1.9 ms, against 1.0 ms now.)
+//   whole packed gamma, bias/beta and the /255 table stay in LDS, each wave keeps the input pixels behind its
+//   own two output rows in a private LDS buffer and fetches the next tile's into registers under the current
+//   tile's MFMAs; after the prologue there is no block barrier.  (The one-tile-per-block form re-read 120 KB
+//   of weights and gamma per 128 output pixels and exposed its whole prologue: 1.9 ms per 32 tiles.)
 //   The output write (fp32-sized split rows, 134 MB per 1024x1024 tile) bounds this layer.
 // =================================================================================================
 template <int KS, int CT, bool GDN>
@@ -366,12 +367,15 @@ struct FirstGeomF16 {
     static constexpr int NS = (KS * KS + 3) / 4;  // k-steps of 4 taps
     static constexpr int W_BYTES = NS * CT * 2048;
     static constexpr int G_BYTES = GDN ? CT * CT * 4096 : 0;
-    static constexpr int HALO_BYTES = ((HH * WH * 16 + 1023) / 1024) * 1024;
+    // wave-private halo: the KS+2 input rows x WH columns behind a wave's two output rows.  Private buffers need no
+    // block barrier per tile (the waves drift apart, so one wave's split / store work overlaps another's MFMAs) and
+    // no double buffer (the wave that reads a buffer is the one that refills it).
+    static constexpr int RH = KS + 2;
+    static constexpr int WAVE_HALO_BYTES = ((RH * WH * 16 + 1023) / 1024) * 1024;
     static constexpr int VEC_BYTES = 1024 + ((2 * CT * 32 * 4 + 1023) / 1024) * 1024;  // /255 table | bias | beta
     static constexpr int FIXED_BYTES = G_BYTES + W_BYTES + VEC_BYTES;
-    static constexpr int NBUF = FIXED_BYTES + 2 * HALO_BYTES <= 160 * 1024 ? 2 : 1;
-    static constexpr int LDS_BYTES = FIXED_BYTES + NBUF * HALO_BYTES;
-    static constexpr int NPOS = (HH * WH + NW * 64 - 1) / (NW * 64);  // halo pixels per thread
+    static constexpr int LDS_BYTES = FIXED_BYTES + NW * WAVE_HALO_BYTES;
+    static constexpr int NPOS = (RH * WH + 63) / 64;  // halo pixels per lane
 };
 
 template <int KS, int CT, bool GDN, bool U8>
@@ -404,9 +408,9 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
         beta_lds[i] = (GDN && p.beta) ? p.beta[i] : 1.0f;
     }
 
-    // next tile's input pixels, raw (4 bytes or 4 floats per pixel).  Branch-free on purpose: every load is
-    // issued unconditionally (clamped pixel / channel index) so that all of them stay in flight under the
-    // current tile's MFMAs; absent channels are zeroed when the values are committed to LDS.
+    // next tile's input pixels of THIS WAVE's halo, raw (4 bytes or 4 floats per pixel).  Branch-free on purpose:
+    // every load is issued unconditionally (clamped pixel / channel index) so that all of them stay in flight under
+    // the current tile's MFMAs; absent channels are zeroed when the values are committed to LDS.
     // (the input format is a template parameter so that the loaded registers have a single definition: with a
     //  run-time format the compiler joined the two load paths and waited for the data right after issuing)
     typedef typename std::conditional<U8, uint8_t, float>::type raw_t;
@@ -417,10 +421,11 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
 #pragma unroll
         for (int k = 0; k < G::NPOS; ++k) {
-            int i = threadIdx.x + k * NW * 64;
-            i = i < HH * WH ? i : HH * WH - 1;
+            int i = lane + k * 64;
+            i = i < G::RH * WH ? i : G::RH * WH - 1;
             const int r = i / WH, x = i - r * WH;
-            const int iy = reflect_idx(2 * ty * TY - PAD + r, p.H), ix = reflect_idx(2 * tx * TX - PAD + x, p.W);
+            const int iy = reflect_idx(2 * (ty * TY + 2 * wave) - PAD + r, p.H);
+            const int ix = reflect_idx(2 * tx * TX - PAD + x, p.W);
             if constexpr (U8) {
                 const uint8_t *src = (const uint8_t *)f.in + (((size_t)n * p.H + iy) * p.W + ix) * f.cin;
 #pragma unroll
@@ -432,11 +437,12 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
             }
         }
     };
-    auto commit = [&](char *hb) {  // exact x/255 through the table
+    char *whalo = hbuf + wave * G::WAVE_HALO_BYTES;
+    auto commit = [&]() {  // exact x/255 through the table
 #pragma unroll
         for (int k = 0; k < G::NPOS; ++k) {
-            const int i = threadIdx.x + k * NW * 64;
-            if (i < HH * WH) {
+            const int i = lane + k * 64;
+            if (i < G::RH * WH) {
                 f32x4 v;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -444,22 +450,22 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
                     if constexpr (U8) val = lut[raw[k][c]]; else val = raw[k][c];
                     v[c] = c <= c_last ? val : 0.0f;
                 }
-                *(f32x4 *)(hb + i * 16) = v;
+                *(f32x4 *)(whalo + i * 16) = v;
             }
         }
     };
 
     int t = blockIdx.x;
     if (t < total) fetch(t);
-    __syncthreads();  // table visible
-    if (t < total) commit(hbuf);
     wait_vm0();
-    __syncthreads();
+    __syncthreads();  // resident operands and the table visible to every wave; the only block barrier
+    if (t < total) commit();
+    __builtin_amdgcn_wave_barrier();
 
-    const int wrow = 2 * wave + (m >> 4);
-    const int hb_off = ((2 * wrow) * WH + 2 * (m & 15)) * 16;
+    const char *hb = whalo + ((2 * (m >> 4)) * WH + 2 * (m & 15)) * 16;
     const char *wb = wbuf + lane * 16;
-    int cur = 0;
+    // (starting the two waves of a SIMD half a tile period apart, so that one's VALU phase meets the other's MFMA
+    //  phase, was measured: no effect -- profiles/r01_experiments.md)
     for (; t < total; t += gridDim.x) {
         const int tn = t + gridDim.x;
         const bool has_next = tn < total;
@@ -467,7 +473,6 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
 
         const int n = t / tiles_img, rem = t - n * tiles_img;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const char *hb = hbuf + cur * G::HALO_BYTES + hb_off;
         f32x16 acc[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -502,13 +507,14 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
             }
         }
         if constexpr (GDN) gdn_resident_f16<CT, false>(acc, gbuf, beta_lds, lane);
-        const int oy = ty * TY + wrow, ox = tx * TX + (m & 15);
+        const int oy = ty * TY + 2 * wave + (m >> 4), ox = tx * TX + (m & 15);
         store_tiles_f16<CT>(acc, p, n, oy, ox, h, oy < p.OH && ox < p.OW);
 
-        if (G::NBUF == 1) __syncthreads();  // single halo buffer: everyone is done reading it
-        if (has_next) commit(hbuf + (G::NBUF == 2 ? (cur ^ 1) : 0) * G::HALO_BYTES);
-        __syncthreads();
-        cur ^= G::NBUF - 1;
+        // refill this wave's halo: LDS operations of one wave execute in order, the wave barriers only keep the
+        // compiler from moving the stores above the reads of the tile just finished (or the next reads above them)
+        __builtin_amdgcn_wave_barrier();
+        if (has_next) commit();
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
