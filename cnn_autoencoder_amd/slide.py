@@ -74,6 +74,11 @@ def slide_summary(stats: torch.Tensor, pixels_per_tile: int) -> Dict[str, float]
                 mse=mse, rmse=math.sqrt(mse), psnr=(10.0 * math.log10(255.0 ** 2 / mse) if mse > 0 else float('inf')))
 
 
+def _dev():
+    from . import _lib
+    return _lib.require_gpu()
+
+
 class SlideCoder:
     """Batched compress -> decompress of resident tile batches on this rank's GPU.
 
@@ -92,6 +97,7 @@ class SlideCoder:
         self.coder_threads = coder_threads
         self.depth = 3  # batches the analysis runs ahead of the synthesis in run()
         self._pinned = {}
+        self._busy = {}  # pinned buffer key -> event of the asynchronous copy that is still reading it
         self._copy_stream = None
         self.timers = {}
 
@@ -131,6 +137,137 @@ class SlideCoder:
         sse = self.tile_sse(rec, tiles_dev).cpu()
         stats = tile_stats([len(p) + 16 for p in payloads], sse.tolist(), h * w * c)
         return payloads, rec, stats
+
+    # ---- pipelined one-way streams (what compress.py / decompress.py do: encode only, decode only) ------------
+    def _to_device(self, batch, k, stream):
+        """A (n,h,w,c) uint8 batch on the GPU: CUDA tensors pass through, host arrays go through a pinned staging
+        buffer and an asynchronous H2D on `stream`.  -> (tensor, event | None)."""
+        if isinstance(batch, torch.Tensor) and batch.is_cuda:
+            return batch, None
+        arr = batch.numpy() if isinstance(batch, torch.Tensor) else np.ascontiguousarray(batch)
+        if arr.dtype != np.uint8 or arr.ndim != 4:
+            raise ValueError(f'expected a (n,h,w,c) uint8 batch, got {arr.dtype} {arr.shape}')
+        key = ('t', k % (self.depth + 1))
+        pin = self._pin(key, arr.shape, torch.uint8)
+        self._wait_free(key)  # the H2D that last read this staging buffer
+        pin.numpy()[...] = arr
+        with torch.cuda.stream(stream):
+            dev = pin.to(_dev(), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        self._busy[key] = ev
+        return dev, ev
+
+    def _wait_free(self, key):
+        ev = self._busy.pop(key, None)
+        if ev is not None:
+            ev.synchronize()
+
+    @torch.no_grad()
+    def compress_batches(self, batches):
+        """Generator: for every (n,h,w,c) uint8 batch (CUDA tensor or host array) the list of rANS payloads (without
+        the 16-byte chunk header), in order.  The GPU analyses up to `depth` batches ahead while a host worker pulls
+        the symbols over the DMA engines and range-encodes them."""
+        from concurrent.futures import ThreadPoolExecutor
+        from . import _lib
+        main = torch.cuda.current_stream(_dev())
+        if self._copy_stream is None:
+            self._copy_stream = (torch.cuda.Stream(_dev()), torch.cuda.Stream(_dev()))
+        up = self._copy_stream[1]
+        depth = self.depth
+
+        def stage(k, batch):
+            t, ev = self._to_device(batch, k, up)
+            if ev is not None:
+                main.wait_event(ev)
+                t.record_stream(main)
+            sym = self.enc.forward_u8_symbols(t, self.eb)
+            n, C = sym.size(0), sym.size(1)
+            hw = sym.numel() // (n * C)
+            pin = self._pin(('a', k % (depth + 1)), (n, C, hw), torch.int32)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            return pin, ready, sym
+
+        def encode(pin, ready, sym):
+            ready.synchronize()
+            _lib.check(_lib.lib().cae_copy_to_host(pin.data_ptr(), sym.data_ptr(), sym.numel() * 4))
+            del sym
+            return self.eb.encode_symbols(pin.numpy(), self.coder_threads)
+
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            inflight = []
+            for k, batch in enumerate(batches):
+                inflight.append(pool.submit(encode, *stage(k, batch)))
+                if len(inflight) > depth:
+                    yield inflight.pop(0).result()
+            while inflight:
+                yield inflight.pop(0).result()
+
+    @torch.no_grad()
+    def decompress_batches(self, payload_batches, h: int, w: int, to_host: bool = False):
+        """Generator: for every list of rANS payloads (tiles of h x w pixels) the (n,h,w,c) uint8 reconstruction, in
+        order: a CUDA tensor, or with ``to_host`` a numpy array in a pinned ring buffer that stays valid until the
+        generator has advanced two more times.  A host worker range-decodes up to `depth` batches ahead into pinned
+        memory, H2D runs on a side stream beside the synthesis kernels, and with ``to_host`` a second worker pulls
+        each reconstruction over the DMA engines while the next batch is synthesised."""
+        from concurrent.futures import ThreadPoolExecutor
+        from . import _lib
+        main = torch.cuda.current_stream(_dev())
+        if self._copy_stream is None:
+            self._copy_stream = (torch.cuda.Stream(_dev()), torch.cuda.Stream(_dev()))
+        up = self._copy_stream[1]
+        depth = self.depth
+        lh, lw = h // 2 ** self.level, w // 2 ** self.level
+        C = self.eb.channels
+
+        def decode(k, payloads):
+            key = ('d', k % (depth + 2))
+            back = self._pin(key, (len(payloads), C, lh * lw), torch.int32)
+            self._wait_free(key)  # the H2D that last read this buffer
+            self.eb.decode_symbols(payloads, lh * lw, self.coder_threads, out=back.numpy())
+            return key, back
+
+        def synth(item):
+            key, back = item
+            with torch.cuda.stream(up):
+                sym = back.to(_dev(), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(up)
+            self._busy[key] = ev
+            main.wait_event(ev)
+            sym.record_stream(main)
+            return self.dec.forward_symbols_u8(sym.reshape(sym.size(0), C, lh, lw), self.eb)
+
+        def fetch(j, rec, done):
+            out = self._pin(('o', j % 4), tuple(rec.shape), torch.uint8)
+            done.synchronize()
+            _lib.check(_lib.lib().cae_copy_to_host(out.data_ptr(), rec.data_ptr(), rec.numel()))
+            return out.numpy()
+
+        with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=1) as out_pool:
+            inflight, outgoing, j = [], [], 0
+
+            def emit(item):
+                nonlocal j
+                rec = synth(item)
+                if not to_host:
+                    return [rec]
+                done = torch.cuda.Event()
+                done.record(main)
+                outgoing.append(out_pool.submit(fetch, j, rec, done))
+                j += 1
+                # one reconstruction stays in flight: its D2H overlaps the next batch's synthesis
+                return [outgoing.pop(0).result()] if len(outgoing) > 1 else []
+
+            for k, payloads in enumerate(payload_batches):
+                inflight.append(pool.submit(decode, k, list(payloads)))
+                if len(inflight) > depth:
+                    yield from emit(inflight.pop(0).result())
+            while inflight:
+                yield from emit(inflight.pop(0).result())
+            while outgoing:
+                yield outgoing.pop(0).result()
 
     # ---- pipelined slide pass ----------------------------------------------------------------
     def _pin(self, key, shape, dtype):

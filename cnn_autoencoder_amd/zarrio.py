@@ -273,14 +273,19 @@ def compress_image(codec: str, checkpoint, image: np.ndarray, output_filename: s
                          codec=compressor, write_meta=rank == 0)
     tiles = z.chunk_indices()
     lo, hi = slide.tile_range(rank, world, len(tiles))
-    for group in _batches(tiles[lo:hi], batch_tiles):
-        if isinstance(compressor, ConvolutionalAutoencoder):
-            batch = np.stack([z.pad_chunk(image[z.chunk_slices(i)]) for i in group])
-            for idx, cdata in zip(group, compressor.encode_batch(batch)):
-                z.write_chunk_bytes(idx, cdata)
-        else:
-            for idx in group:
-                z.write_chunk(idx, image[z.chunk_slices(idx)])
+    if isinstance(compressor, ConvolutionalAutoencoder):
+        # pipelined: the GPU analyses the next batches while a host worker range-encodes and this thread writes files
+        import struct
+        groups = list(_batches(tiles[lo:hi], batch_tiles))
+        coder = slide.SlideCoder(compressor)
+        stream = coder.compress_batches(np.stack([z.pad_chunk(image[z.chunk_slices(i)]) for i in g]) for g in groups)
+        head = struct.pack('>QQ', patch_size, patch_size)  # chunk = '>QQ'(h, w) + rANS payload (_autoencoders.py:553-555)
+        for group, payloads in zip(groups, stream):
+            for idx, payload in zip(group, payloads):
+                z.write_chunk_bytes(idx, head + payload)
+        return z
+    for idx in tiles[lo:hi]:
+        z.write_chunk(idx, image[z.chunk_slices(idx)])
     return z
 
 
@@ -292,12 +297,26 @@ def decompress_image(input_filename: str, data_group: str = '0/0', checkpoint=No
     z = ZarrArray.open(input_filename, data_group)
     if checkpoint is None or (isinstance(checkpoint, str) and not len(checkpoint)):
         if isinstance(z.codec, ConvolutionalAutoencoder):
+            # pipelined: a host worker range-decodes the next batches while the GPU synthesises
+            import struct
+            from . import slide
             out = np.empty(z.shape, dtype=z.dtype)
-            for group in _batches(z.chunk_indices(), batch_tiles):
+            groups = list(_batches(z.chunk_indices(), batch_tiles))
+            ph, pw = z.chunks[0], z.chunks[1]
+
+            def payloads(group):
                 bufs = [z.read_chunk_bytes(i) for i in group]
                 if any(b is None for b in bufs):
                     raise ValueError('missing chunk file')
-                for idx, chunk in zip(group, z.codec.decode_batch(bufs)):
+                for b in bufs:
+                    if struct.unpack('>QQ', b[:16]) != (ph, pw):
+                        raise ValueError('chunk header does not match the chunk shape')
+                return [b[16:] for b in bufs]
+
+            coder = slide.SlideCoder(z.codec)
+            stream = coder.decompress_batches((payloads(g) for g in groups), ph, pw, to_host=True)
+            for group, rec in zip(groups, stream):  # rec: pinned ring buffer, copied out right away
+                for idx, chunk in zip(group, rec):
                     sl = z.chunk_slices(idx)
                     out[sl] = chunk[tuple(slice(0, s.stop - s.start) for s in sl)]
             return out

@@ -358,6 +358,26 @@ def test_fused_quantiser_entry_points_equal_the_unfused_path(cae):
     assert torch.equal(rec, dec.forward_u8(eb.dequantize_symbols(sym)))
 
 
+def test_one_way_streams_equal_the_simple_calls(cae):
+    """SlideCoder.compress_batches / decompress_batches (pipelined encode-only and decode-only streams, host or
+    device input) give the payloads / reconstructions of the unpipelined compress() / decompress()."""
+    from cnn_autoencoder_amd import slide, synth
+    state = synth.synthetic_state(dict(synth.CANONICAL, channels_net=32, channels_bn=48), seed=6)
+    codec = cae.ConvolutionalAutoencoder(checkpoint=state)
+    coder = slide.SlideCoder(codec)
+    coder.depth = 2
+    batches = [synth.uniform_tiles(3, 64, 96) for _ in range(7)]
+    batches[3] = torch.from_numpy(batches[3]).cuda()  # device input passes through
+    want = [coder.compress(b if isinstance(b, torch.Tensor) else torch.from_numpy(b).cuda()) for b in batches]
+    got = list(coder.compress_batches(iter(batches)))
+    assert got == want
+    rec_want = [coder.decompress(p, 64, 96) for p in want]
+    rec_got = list(coder.decompress_batches(iter(want), 64, 96))
+    assert len(rec_got) == 7 and all(torch.equal(a, b) for a, b in zip(rec_got, rec_want))
+    host = [r.copy() for r in coder.decompress_batches(iter(want), 64, 96, to_host=True)]  # ring buffers: copy at once
+    assert len(host) == 7 and all(np.array_equal(a, b.cpu().numpy()) for a, b in zip(host, rec_want))
+
+
 def test_tile_sse_exact(cae):
     from cnn_autoencoder_amd import slide, synth
     rng = np.random.default_rng(0)
