@@ -189,16 +189,18 @@ class SlideCoder:
             ready.record(main)
             return pin, ready, sym
 
-        def encode(pin, ready, sym):
+        def pull(pin, ready, sym):  # worker 1: DMA-engine D2H of batch k+1 while worker 2 encodes batch k
             ready.synchronize()
             _lib.check(_lib.lib().cae_copy_to_host(pin.data_ptr(), sym.data_ptr(), sym.numel() * 4))
-            del sym
-            return self.eb.encode_symbols(pin.numpy(), self.coder_threads)
+            return pin
 
-        with ThreadPoolExecutor(max_workers=1) as pool:
+        def encode(pulled):
+            return self.eb.encode_symbols(pulled.result().numpy(), self.coder_threads)
+
+        with ThreadPoolExecutor(max_workers=1) as d2h_pool, ThreadPoolExecutor(max_workers=1) as pool:
             inflight = []
             for k, batch in enumerate(batches):
-                inflight.append(pool.submit(encode, *stage(k, batch)))
+                inflight.append(pool.submit(encode, d2h_pool.submit(pull, *stage(k, batch))))
                 if len(inflight) > depth:
                     yield inflight.pop(0).result()
             while inflight:
