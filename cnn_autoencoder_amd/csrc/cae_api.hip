@@ -993,15 +993,31 @@ int cae_gdn_forward(cae_model_t *mm, int track, int index, const float *x, int n
 int cae_tile_sse(const uint8_t *a, const uint8_t *b, int n, size_t elems, double *sse, void *stream) {
     if (!a || !b || !sse) return fail(CAE_ERR_ARG, "NULL argument");
     if (n < 1 || elems < 1) return fail(CAE_ERR_ARG, "bad shape");
-    if (((uintptr_t)a | (uintptr_t)b) & 15 || (elems & 15)) return fail(CAE_ERR_ARG, "tiles must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     // the float64 output doubles as the exact integer accumulator (same 8-byte cells)
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(sse);
     HIP_TRY(hipMemsetAsync(acc, 0, (size_t)n * 8, st));
-    const unsigned bx = (unsigned)std::min<size_t>(std::max<size_t>(elems / 16 / 256, 1), 64);
+    const unsigned bx = (unsigned)std::min<size_t>(std::max<size_t>(elems / 16 / 256, 1), 64);  // (byte loop: same grid)
     hipLaunchKernelGGL(tile_sse_kernel, dim3(bx, n), dim3(256), 0, st, a, b, elems, acc);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(u64_to_f64_kernel, dim3((n + 255) / 256), dim3(256), 0, st, acc, sse, n);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_tile_ssim(const uint8_t *a, const uint8_t *b, int n, int h, int w, int c, double *ssim, double *workspace,
+                  size_t workspace_elems, void *stream) {
+    if (!a || !b || !ssim || !workspace) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || n > 65535 || c < 1) return fail(CAE_ERR_ARG, "bad shape");
+    if (h < 7 || w < 7) return fail(CAE_ERR_ARG, "tiles must be at least 7x7 (the SSIM window)");
+    const int oh = h - 6, ow = w - 6;
+    const int bxr = (ow + 31) / 32, bpt = bxr * ((oh + 31) / 32);
+    if (workspace_elems < (size_t)n * bpt)
+        return fail(CAE_ERR_ARG, "workspace too small: %zu doubles needed", (size_t)n * bpt);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tile_ssim_kernel, dim3(bpt, n), dim3(256), 0, st, a, b, h, w, c, bxr, bpt, workspace);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(ssim_reduce_kernel, dim3(n), dim3(256), 0, st, workspace, bpt, (double)oh * ow * c, ssim);
     HIP_TRY(hipGetLastError());
     return CAE_OK;
 }

@@ -1008,7 +1008,9 @@ static __global__ void tile_sse_kernel(const uint8_t *a, const uint8_t *b, size_
     const int tile = blockIdx.y;
     const uint8_t *pa = a + (size_t)tile * elems, *pb = b + (size_t)tile * elems;
     unsigned long long acc = 0;
-    const size_t nvec = elems / 16;
+    // 16-byte vector loads when both tiles are 16-byte aligned, else a plain byte loop (ragged tile sizes)
+    const bool vec = ((((uintptr_t)pa) | ((uintptr_t)pb)) & 15) == 0;
+    const size_t nvec = vec ? elems / 16 : 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
         const uint4 va = ((const uint4 *)pa)[i], vb = ((const uint4 *)pb)[i];
         const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
@@ -1022,14 +1024,113 @@ static __global__ void tile_sse_kernel(const uint8_t *a, const uint8_t *b, size_
             }
         acc += s;
     }
-    if (blockIdx.x == 0)
-        for (size_t i = nvec * 16 + threadIdx.x; i < elems; i += blockDim.x) {
+    if (vec) {
+        if (blockIdx.x == 0)
+            for (size_t i = nvec * 16 + threadIdx.x; i < elems; i += blockDim.x) {
+                const int d = (int)pa[i] - (int)pb[i];
+                acc += (unsigned)(d * d);
+            }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
             const int d = (int)pa[i] - (int)pb[i];
             acc += (unsigned)(d * d);
         }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(out + tile, acc);
+}
+
+// ---- SSIM of two uint8 HWC tile batches (skimage.metrics.structural_similarity as the reference's harness calls it,
+// test_cae.py:55-57: 7x7 uniform window, sample covariance, K1 = 0.01, K2 = 0.03, data range 255, 3-pixel border cropped,
+// mean over channels).  The five window sums are exact integers; the per-pixel index is evaluated in float64.
+// Block = 32x32 output pixels of one tile: rows of horizontal 7-sums in LDS, then vertical 7-sums per thread.
+static __global__ void __launch_bounds__(256)
+tile_ssim_kernel(const uint8_t *a, const uint8_t *b, int H, int W, int C, int bx_per_row, int blocks_per_tile,
+                 double *part) {
+    constexpr int T = 32, WIN = 7, IN = T + WIN - 1;
+    __shared__ uint8_t sa[IN][IN + 2], sb[IN][IN + 2];
+    __shared__ int hs[5][IN][T];
+    __shared__ double red[256];
+    const int tile = blockIdx.y, blk = blockIdx.x;
+    const int by = blk / bx_per_row, bx = blk - by * bx_per_row;
+    const int oy0 = by * T, ox0 = bx * T;       // output (= top-left input) coordinates of this block
+    const int OH = H - WIN + 1, OW = W - WIN + 1;  // valid outputs
+    const size_t base = (size_t)tile * H * W * C;
+    const double C1 = (0.01 * 255.0) * (0.01 * 255.0), C2 = (0.03 * 255.0) * (0.03 * 255.0);
+    const double cov_norm = 49.0 / 48.0;
+    double acc = 0.0;
+    for (int c = 0; c < C; ++c) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < IN * IN; i += 256) {
+            const int r = i / IN, x = i - r * IN;
+            const int iy = oy0 + r, ix = ox0 + x;
+            const bool ok = iy < H && ix < W;
+            const size_t off = base + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * C + c;
+            sa[r][x] = ok ? a[off] : 0;
+            sb[r][x] = ok ? b[off] : 0;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < IN * T; i += 256) {
+            const int r = i / T, x = i - r * T;
+            int s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) {
+                const int u = sa[r][x + k], v = sb[r][x + k];
+                s0 += u;
+                s1 += v;
+                s2 += u * u;
+                s3 += v * v;
+                s4 += u * v;
+            }
+            hs[0][r][x] = s0;
+            hs[1][r][x] = s1;
+            hs[2][r][x] = s2;
+            hs[3][r][x] = s3;
+            hs[4][r][x] = s4;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < T * T; i += 256) {
+            const int y = i / T, x = i - y * T;
+            if (oy0 + y < OH && ox0 + x < OW) {
+                int s[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < WIN; ++k)
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) s[q] += hs[q][y + k][x];
+                const double ux = s[0] / 49.0, uy = s[1] / 49.0;
+                const double vx = cov_norm * (s[2] / 49.0 - ux * ux), vy = cov_norm * (s[3] / 49.0 - uy * uy);
+                const double vxy = cov_norm * (s[4] / 49.0 - ux * uy);
+                const double A1 = 2.0 * ux * uy + C1, A2 = 2.0 * vxy + C2;
+                const double B1 = ux * ux + uy * uy + C1, B2 = vx + vy + C2;
+                acc += (A1 * A2) / (B1 * B2);
+            }
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(size_t)tile * blocks_per_tile + blk] = red[0];
+}
+
+// ssim[tile] = sum of the block partials (fixed order) / number of (pixel, channel) samples
+static __global__ void ssim_reduce_kernel(const double *part, int blocks_per_tile, double samples, double *ssim) {
+    __shared__ double red[256];
+    const int tile = blockIdx.x;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < blocks_per_tile; i += 256) v += part[(size_t)tile * blocks_per_tile + i];
+    red[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ssim[tile] = red[0] / samples;
 }
 
 static __global__ void u64_to_f64_kernel(const unsigned long long *in, double *out, int n) {

@@ -170,6 +170,13 @@ int cae_model_set_density(cae_model_t *m, int channels, int n_filters, const int
 int cae_likelihood(cae_model_t *m, const float *latents_dev, int n, int hw, float *y_hat_dev,
                    float *likelihood_dev, double *bits_dev, void *stream);
 
+/* Mean structural similarity of two (n, h, w, c) uint8 HWC batches -> ssim_dev[n] (float64): the algorithm of
+ * skimage.metrics.structural_similarity(x, x_r, channel_axis=2) as the reference's metrics harness calls it
+ * (test_cae.py:55-57): 7x7 uniform window, sample covariance, K1 = 0.01, K2 = 0.03, data range 255, 3-pixel border
+ * cropped, mean over channels.  workspace_dev: n * ceil((h-6)/32) * ceil((w-6)/32) doubles. */
+int cae_tile_ssim(const uint8_t *a_dev, const uint8_t *b_dev, int n, int h, int w, int c, double *ssim_dev,
+                  double *workspace_dev, size_t workspace_elems, void *stream);
+
 /* Blocking device -> pinned-host copy on the DMA engines (hsa_amd_memory_async_copy), for symbols on their way
  * to the host coder.  The caller has already waited for the kernels that produce `src_dev` (event / stream
  * synchronise); safe to call from any host thread.  hipMemcpyAsync is not used because the HIP runtime bundled

@@ -487,3 +487,34 @@ def codec_decode(buf: bytes, dec_layers, eb: EntropyBottleneckOracle, decode_fn=
     yq = eb.decompress([buf[16:]], size, decode_fn)
     x_r, _ = synthesis_forward(yq, dec_layers)
     return output_to_tile(x_r[0])
+
+
+# --------------------------------------------------------------------------------------
+# Metrics of the reference's harness (src/test_cae.py:47-73)
+# --------------------------------------------------------------------------------------
+def ssim_uint8(x: np.ndarray, x_r: np.ndarray) -> float:
+    """skimage.metrics.structural_similarity(x, x_r, channel_axis=2) for uint8 (H, W, C) images, as called at
+    test_cae.py:55-57.  skimage is absent from this image ("parity unpinned"): restated from the published
+    algorithm -- float64, 7x7 uniform window (scipy.ndimage.uniform_filter), sample covariance (NP/(NP-1)),
+    K1 = 0.01, K2 = 0.03, data range 255, crop (win-1)//2 = 3 pixels, mean per channel, then mean over channels."""
+    from scipy.ndimage import uniform_filter
+    win, k1, k2, rng = 7, 0.01, 0.03, 255.0
+    npx = win * win
+    cov_norm = npx / (npx - 1.0)
+    c1, c2 = (k1 * rng) ** 2, (k2 * rng) ** 2
+    pad = (win - 1) // 2
+    vals = []
+    for c in range(x.shape[2]):
+        a, b = x[..., c].astype(np.float64), x_r[..., c].astype(np.float64)
+        ux, uy = uniform_filter(a, size=win), uniform_filter(b, size=win)
+        uxx, uyy, uxy = uniform_filter(a * a, size=win), uniform_filter(b * b, size=win), uniform_filter(a * b, size=win)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
+        vals.append(s[pad:-pad, pad:-pad].mean(dtype=np.float64))
+    return float(np.mean(vals))
+
+
+def psnr_uint8(x: np.ndarray, x_r: np.ndarray, max_val: float = 255.0) -> float:
+    """test_cae.py:60-63 computed in float64 (the reference subtracts uint8 arrays, which wraps: Appendix B)."""
+    mse = np.mean((x.astype(np.float64) - x_r.astype(np.float64)) ** 2)
+    return float(20 * math.log10(max_val) - 10 * math.log10(mse))

@@ -378,6 +378,29 @@ def test_one_way_streams_equal_the_simple_calls(cae):
     assert len(host) == 7 and all(np.array_equal(a, b.cpu().numpy()) for a, b in zip(host, rec_want))
 
 
+def test_metrics_match_the_oracle(cae):
+    """SSIM / PSNR / RMSE per tile on the GPU against the float64 restatements (ragged size, 3 and 1 channels)."""
+    from oracle import cae_oracle as O
+    from cnn_autoencoder_amd import metrics, synth
+    rng = np.random.default_rng(11)
+    for shape in ((3, 70, 101, 3), (2, 64, 64, 1), (1, 7, 9, 3)):
+        x = rng.integers(0, 256, shape, dtype=np.uint8)
+        x[0] = synth.histo_tile(shape[1], 3, shape[2])[..., :shape[3]]
+        y = np.clip(x.astype(int) + rng.integers(-12, 13, shape), 0, 255).astype(np.uint8)
+        xs, ys = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        ssim = metrics.metric_fun['ssim'](x=xs, x_r=ys).cpu().numpy()
+        np.testing.assert_allclose(ssim, [O.ssim_uint8(a, b) for a, b in zip(x, y)], rtol=1e-12)
+        psnr = metrics.metric_fun['psnr'](x=xs, x_r=ys).cpu().numpy()
+        np.testing.assert_allclose(psnr, [O.psnr_uint8(a, b) for a, b in zip(x, y)], rtol=1e-12)
+        rmse = metrics.metric_fun['dist'](x=xs, x_r=ys).cpu().numpy()
+        np.testing.assert_allclose(rmse ** 2, [np.mean((a.astype(float) - b) ** 2) for a, b in zip(x, y)], rtol=1e-12)
+    assert float(metrics.compute_ssim(x=xs, x_r=xs)[0]) == 1.0
+    with pytest.raises(ValueError):
+        metrics.compute_ssim(x=xs[:, :5], x_r=ys[:, :5])
+    with pytest.raises(NotImplementedError):
+        metrics.metric_fun['ms-ssim'](x=xs, x_r=ys)
+
+
 def test_tile_sse_exact(cae):
     from cnn_autoencoder_amd import slide, synth
     rng = np.random.default_rng(0)

@@ -155,3 +155,25 @@ def test_gdn_identity_cases():
     np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
     z = O.gdn_forward(y, b, g, inverse=True)
     assert z.shape == x.shape and torch.isfinite(z).all()
+
+
+def test_ssim_restatement_known_answers():
+    """skimage is absent: the SSIM restatement is held by properties with closed forms -- identical images give 1,
+    a constant offset d between two flat images gives (2 u (u+d) + C1) / (u^2 + (u+d)^2 + C1) exactly (variances 0),
+    symmetry, and an independent direct (loop) evaluation of one window."""
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (24, 31, 3), dtype=np.uint8)
+    y = np.clip(x.astype(int) + rng.integers(-20, 21, x.shape), 0, 255).astype(np.uint8)
+    assert O.ssim_uint8(x, x) == pytest.approx(1.0, abs=1e-15)
+    assert O.ssim_uint8(x, y) == pytest.approx(O.ssim_uint8(y, x), rel=1e-14)
+    flat_a, flat_b = np.full((16, 16, 1), 100, np.uint8), np.full((16, 16, 1), 130, np.uint8)
+    c1 = (0.01 * 255) ** 2
+    assert O.ssim_uint8(flat_a, flat_b) == pytest.approx((2 * 100 * 130 + c1) / (100 ** 2 + 130 ** 2 + c1), rel=1e-13)
+    # one window by hand: 7x7 image -> a single valid... (crop leaves 1x1 at the centre)
+    a, b = x[:7, :7, :1].astype(np.float64), y[:7, :7, :1].astype(np.float64)
+    ux, uy = a.mean(), b.mean()
+    vx, vy = a.var(ddof=1), b.var(ddof=1)
+    vxy = ((a - ux) * (b - uy)).sum() / 48.0
+    c2 = (0.03 * 255) ** 2
+    want = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+    assert O.ssim_uint8(x[:7, :7, :1], y[:7, :7, :1]) == pytest.approx(want, rel=1e-12)
