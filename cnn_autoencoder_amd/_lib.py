@@ -52,6 +52,7 @@ SYMBOLS = {
     'cae_model_set_density': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float]),
     'cae_likelihood': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cae_tile_ssim': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'cae_tile_delta_e': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
     'cae_tile_sse': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
     'cae_model_set_profiling': (c_int, [c_void_p, c_int]),
     'cae_model_get_profile': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]),

@@ -1022,6 +1022,21 @@ int cae_tile_ssim(const uint8_t *a, const uint8_t *b, int n, int h, int w, int c
     return CAE_OK;
 }
 
+int cae_tile_delta_e(const uint8_t *a, const uint8_t *b, int n, size_t pixels, double *delta, double *workspace,
+                     size_t workspace_elems, void *stream) {
+    if (!a || !b || !delta || !workspace) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || n > 65535 || pixels < 1) return fail(CAE_ERR_ARG, "bad shape");
+    const int bpt = (int)std::min<size_t>((pixels + 255) / 256, 128);
+    if (workspace_elems < (size_t)n * bpt)
+        return fail(CAE_ERR_ARG, "workspace too small: %zu doubles needed", (size_t)n * bpt);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tile_delta_e_kernel, dim3(bpt, n), dim3(256), 0, st, a, b, pixels, bpt, workspace);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(ssim_reduce_kernel, dim3(n), dim3(256), 0, st, workspace, bpt, (double)pixels, delta);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
 int cae_model_set_profiling(cae_model_t *mm, int enable) {
     Model *m = reinterpret_cast<Model *>(mm);
     if (!m) return fail(CAE_ERR_ARG, "NULL model");

@@ -1133,6 +1133,50 @@ static __global__ void ssim_reduce_kernel(const double *part, int blocks_per_til
     if (threadIdx.x == 0) ssim[tile] = red[0] / samples;
 }
 
+// ---- mean CIE76 colour difference of two uint8 RGB tile batches (skimage.color rgb2lab + deltaE_cie76 as the
+// reference's harness calls them, test_cae.py:21-45): sRGB -> linear (table of the 256 levels) -> XYZ (sRGB / D65
+// matrix) -> L*a*b* (2-degree D65 white) -> Euclidean distance, all float64; per-block partial sums, fixed order.
+__device__ __forceinline__ void rgb_to_lab(const double *lin, const uint8_t *px, double &L, double &A, double &B) {
+    const double r = lin[px[0]], g = lin[px[1]], b = lin[px[2]];
+    double x = (0.412453 * r + 0.357580 * g + 0.180423 * b) / 0.95047;
+    double y = (0.212671 * r + 0.715160 * g + 0.072169 * b) / 1.0;
+    double z = (0.019334 * r + 0.119193 * g + 0.950227 * b) / 1.08883;
+    x = x > 0.008856 ? cbrt(x) : 7.787 * x + 16.0 / 116.0;
+    y = y > 0.008856 ? cbrt(y) : 7.787 * y + 16.0 / 116.0;
+    z = z > 0.008856 ? cbrt(z) : 7.787 * z + 16.0 / 116.0;
+    L = 116.0 * y - 16.0;
+    A = 500.0 * (x - y);
+    B = 200.0 * (y - z);
+}
+
+static __global__ void __launch_bounds__(256)
+tile_delta_e_kernel(const uint8_t *a, const uint8_t *b, size_t pixels, int blocks_per_tile, double *part) {
+    __shared__ double lin[256];
+    __shared__ double red[256];
+    {
+        const double v = threadIdx.x / 255.0;  // img_as_float, then the sRGB companding inverse
+        lin[threadIdx.x] = v > 0.04045 ? pow((v + 0.055) / 1.055, 2.4) : v / 12.92;
+    }
+    __syncthreads();
+    const int tile = blockIdx.y;
+    const uint8_t *pa = a + (size_t)tile * pixels * 3, *pb = b + (size_t)tile * pixels * 3;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pixels; i += (size_t)blocks_per_tile * 256) {
+        double l0, a0, b0, l1, a1, b1;
+        rgb_to_lab(lin, pa + 3 * i, l0, a0, b0);
+        rgb_to_lab(lin, pb + 3 * i, l1, a1, b1);
+        acc += sqrt((l0 - l1) * (l0 - l1) + (a0 - a1) * (a0 - a1) + (b0 - b1) * (b0 - b1));
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(size_t)tile * blocks_per_tile + blockIdx.x] = red[0];
+}
+
 static __global__ void u64_to_f64_kernel(const unsigned long long *in, double *out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (double)in[i];

@@ -1,9 +1,9 @@
 """GPU metrics of the reference's test harness (src/test_cae.py:47-89) on batches of uint8 tiles resident in HBM.
 
-``metric_fun`` mirrors the reference's table of the same name for the metrics built here: 'dist' (RMSE), 'psnr', 'ssim'
-and 'rate' (bits per pixel).  Each takes ``x`` / ``x_r`` as (n, h, w, c) uint8 CUDA tensors and returns a float64 CUDA
-tensor of per-tile values (the reference loops over one image at a time on the host).  'ms-ssim' and 'delta_cielab'
-(pytorch_msssim / skimage colour conversion) are not built.
+``metric_fun`` mirrors the reference's table of the same name for the metrics built here: 'dist' (RMSE), 'psnr', 'ssim',
+'delta_cielab' and 'rate' (bits per pixel).  Each takes ``x`` / ``x_r`` as (n, h, w, c) uint8 CUDA tensors and returns a float64 CUDA
+tensor of per-tile values (the reference loops over one image at a time on the host).  'delta_cielab' is skimage's rgb2lab + deltaE_cie76
+restated; 'ms-ssim' (pytorch_msssim) is not built.
 """
 from __future__ import annotations
 
@@ -55,6 +55,21 @@ def compute_ssim(x=None, x_r=None, **kwargs) -> torch.Tensor:
     return out
 
 
+@torch.no_grad()
+def compute_deltaCIELAB(x=None, x_r=None, **kwargs) -> torch.Tensor:
+    """test_cae.py:21-45: mean deltaE_cie76(rgb2lab(x), rgb2lab(x_r)) per tile (cae_tile_delta_e); RGB only."""
+    x, x_r = _check_pair(x, x_r)
+    n, h, w, c = x.shape
+    if c != 3:
+        raise ValueError(f'the input array must have size 3 along `channel_axis`, got {tuple(x.shape)}')  # skimage
+    bpt = min((h * w + 255) // 256, 128)
+    ws = torch.empty(n * bpt, dtype=torch.float64, device=x.device)
+    out = torch.empty(n, dtype=torch.float64, device=x.device)
+    _lib.check(_lib.lib().cae_tile_delta_e(x.data_ptr(), x_r.data_ptr(), n, h * w, out.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), _lib.stream_ptr()))
+    return out
+
+
 def compute_rate(x=None, nbytes=None, **kwargs) -> torch.Tensor:
     """test_cae.py:71-73: 8 * stored bytes / pixels, per tile (nbytes: stored chunk sizes)."""
     px = float(x.size(1) * x.size(2))
@@ -68,4 +83,4 @@ def _not_built(name):
 
 
 metric_fun = {'dist': compute_rmse, 'rate': compute_rate, 'ssim': compute_ssim, 'psnr': compute_psnr,
-              'ms-ssim': _not_built('ms-ssim (pytorch_msssim)'), 'delta_cielab': _not_built('delta_cielab (skimage.color)')}
+              'ms-ssim': _not_built('ms-ssim (pytorch_msssim)'), 'delta_cielab': compute_deltaCIELAB}

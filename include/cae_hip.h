@@ -177,6 +177,12 @@ int cae_likelihood(cae_model_t *m, const float *latents_dev, int n, int hw, floa
 int cae_tile_ssim(const uint8_t *a_dev, const uint8_t *b_dev, int n, int h, int w, int c, double *ssim_dev,
                   double *workspace_dev, size_t workspace_elems, void *stream);
 
+/* Mean CIE76 colour difference of two (n, pixels, 3) uint8 RGB batches -> delta_dev[n] (float64): skimage's
+ * rgb2lab (sRGB, D65, 2-degree observer) + deltaE_cie76 + mean, as compute_deltaCIELAB does (test_cae.py:21-45).
+ * workspace_dev: n * min(ceil(pixels/256), 128) doubles. */
+int cae_tile_delta_e(const uint8_t *a_dev, const uint8_t *b_dev, int n, size_t pixels, double *delta_dev,
+                     double *workspace_dev, size_t workspace_elems, void *stream);
+
 /* Blocking device -> pinned-host copy on the DMA engines (hsa_amd_memory_async_copy), for symbols on their way
  * to the host coder.  The caller has already waited for the kernels that produce `src_dev` (event / stream
  * synchronise); safe to call from any host thread.  hipMemcpyAsync is not used because the HIP runtime bundled

@@ -518,3 +518,22 @@ def psnr_uint8(x: np.ndarray, x_r: np.ndarray, max_val: float = 255.0) -> float:
     """test_cae.py:60-63 computed in float64 (the reference subtracts uint8 arrays, which wraps: Appendix B)."""
     mse = np.mean((x.astype(np.float64) - x_r.astype(np.float64)) ** 2)
     return float(20 * math.log10(max_val) - 10 * math.log10(mse))
+
+
+def delta_cielab_uint8(x: np.ndarray, x_r: np.ndarray) -> float:
+    """np.mean(deltaE_cie76(rgb2lab(x), rgb2lab(x_r))) of test_cae.py:21-45 for uint8 RGB images.  skimage is absent
+    ("parity unpinned"): restated from skimage.color.colorconv -- img_as_float, sRGB companding inverse (threshold
+    0.04045), xyz_from_rgb matrix, D65 / 2-degree white (0.95047, 1, 1.08883), f(t) = cbrt(t) above 0.008856 else
+    7.787 t + 16/116, L = 116 fy - 16, a = 500 (fx - fy), b = 200 (fy - fz); float64."""
+    m = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    white = np.array([0.95047, 1.0, 1.08883])
+
+    def lab(img):
+        arr = img.astype(np.float64) / 255.0
+        arr = np.where(arr > 0.04045, np.power((arr + 0.055) / 1.055, 2.4), arr / 12.92)
+        xyz = arr @ m.T / white
+        f = np.where(xyz > 0.008856, np.cbrt(xyz), 7.787 * xyz + 16.0 / 116.0)
+        return np.stack([116.0 * f[..., 1] - 16.0, 500.0 * (f[..., 0] - f[..., 1]), 200.0 * (f[..., 1] - f[..., 2])], -1)
+
+    d = lab(x) - lab(x_r)
+    return float(np.mean(np.sqrt((d * d).sum(-1))))

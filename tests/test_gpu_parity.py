@@ -394,6 +394,9 @@ def test_metrics_match_the_oracle(cae):
         np.testing.assert_allclose(psnr, [O.psnr_uint8(a, b) for a, b in zip(x, y)], rtol=1e-12)
         rmse = metrics.metric_fun['dist'](x=xs, x_r=ys).cpu().numpy()
         np.testing.assert_allclose(rmse ** 2, [np.mean((a.astype(float) - b) ** 2) for a, b in zip(x, y)], rtol=1e-12)
+        if shape[3] == 3:
+            de = metrics.metric_fun['delta_cielab'](x=xs, x_r=ys).cpu().numpy()
+            np.testing.assert_allclose(de, [O.delta_cielab_uint8(a, b) for a, b in zip(x, y)], rtol=1e-11)
     assert float(metrics.compute_ssim(x=xs, x_r=xs)[0]) == 1.0
     with pytest.raises(ValueError):
         metrics.compute_ssim(x=xs[:, :5], x_r=ys[:, :5])

@@ -177,3 +177,15 @@ def test_ssim_restatement_known_answers():
     c2 = (0.03 * 255) ** 2
     want = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
     assert O.ssim_uint8(x[:7, :7, :1], y[:7, :7, :1]) == pytest.approx(want, rel=1e-12)
+
+
+def test_delta_cielab_restatement_known_answers():
+    """Closed forms: white is L*=100, a*=b*=0 (so black vs white is 100), identical images give 0, and sRGB pure red is
+    the textbook (53.24, 80.09, 67.20) for this matrix / white point."""
+    white, black = np.full((4, 5, 3), 255, np.uint8), np.zeros((4, 5, 3), np.uint8)
+    assert O.delta_cielab_uint8(white, white) == 0.0
+    assert O.delta_cielab_uint8(white, black) == pytest.approx(100.0, abs=2e-3)
+    red = np.zeros((2, 2, 3), np.uint8)
+    red[..., 0] = 255
+    # distance red -> black = |Lab(red)| since Lab(black) = 0
+    assert O.delta_cielab_uint8(red, np.zeros_like(red)) == pytest.approx(np.sqrt(53.24 ** 2 + 80.09 ** 2 + 67.20 ** 2), abs=0.05)
