@@ -404,6 +404,35 @@ def test_metrics_match_the_oracle(cae):
         metrics.metric_fun['ms-ssim'](x=xs, x_r=ys)
 
 
+def test_validation_objective_matches_cpu_restatement(cae):
+    """forward_func + GeneralLoss (rate + lambda * 255^2 * MSE, the `valid` half of the training loop) on the HIP
+    path against the same formulas on the oracle's torch-CPU tensors."""
+    from oracle import cae_oracle as O
+    from cnn_autoencoder_amd import criteria, synth
+    cfg = dict(synth.CANONICAL, channels_net=32, channels_bn=48, compression_level=3)
+    state = synth.synthetic_state(cfg, seed=8)
+    model = cae.autoencoder_from_state_dict(state)
+    x = torch.rand(2, 3, 48, 80)
+    with torch.no_grad():
+        out = criteria.setup_forward_func()(x.cuda(), model)
+        loss = criteria.GeneralLoss(distortion_lambda=0.01)(x.cuda(), out, net=model)
+    # oracle: same state, torch-CPU
+    y, _ = O.analysis_forward(x, oracle_layers(state, 'encoder'))
+    eb = O.EntropyBottleneckOracle(48)
+    eb.load({k: v.cpu() for k, v in model['fact_ent'].module.state_dict().items()})
+    y_q, p = eb.forward(y)
+    x_r, _ = O.synthesis_forward(y_q, oracle_layers(state, 'decoder'))
+    rate = -torch.log2(p.double()).sum() / (2 * 48 * 80)
+    dist = 255 ** 2 * torch.mean((x_r - x) ** 2)
+    assert float(loss['rate_loss']) == pytest.approx(float(rate), rel=1e-4)
+    assert float(loss['dist'][0]) == pytest.approx(float(dist), rel=1e-4)
+    assert float(loss['loss']) == pytest.approx(float(rate + 0.01 * dist), rel=1e-4)
+    assert float(loss['entropy_loss']) == pytest.approx(float(eb.loss()), rel=1e-5)
+    assert out['t_pred'] is None and len(out['x_r']) == 3 and out['y_q'].shape == out['p_y'].shape
+    with pytest.raises(NotImplementedError):  # no backward through the HIP tracks
+        criteria.setup_forward_func()(x.cuda(), model)
+
+
 def test_tile_sse_exact(cae):
     from cnn_autoencoder_amd import slide, synth
     rng = np.random.default_rng(0)
