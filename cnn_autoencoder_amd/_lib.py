@@ -53,6 +53,9 @@ SYMBOLS = {
     'cae_likelihood': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cae_tile_ssim': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'cae_tile_delta_e': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'cae_u8hwc_to_planes': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cae_avgpool2': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cae_msssim_level': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'cae_tile_sse': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
     'cae_model_set_profiling': (c_int, [c_void_p, c_int]),
     'cae_model_get_profile': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]),

@@ -1037,6 +1037,42 @@ int cae_tile_delta_e(const uint8_t *a, const uint8_t *b, int n, size_t pixels, d
     return CAE_OK;
 }
 
+int cae_u8hwc_to_planes(const uint8_t *tiles, int n, int h, int w, int c, float *planes, void *stream) {
+    if (!tiles || !planes) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 1 || w < 1 || c < 1) return fail(CAE_ERR_ARG, "bad shape");
+    hipLaunchKernelGGL(u8hwc_to_planes_kernel, dim3(ew_grid((size_t)n * c * h * w)), dim3(256), 0, (hipStream_t)stream,
+                       tiles, planes, n, h, w, c);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_avgpool2(const float *in, int planes, int h, int w, float *out, void *stream) {
+    if (!in || !out) return fail(CAE_ERR_ARG, "NULL argument");
+    if (planes < 1 || h < 1 || w < 1) return fail(CAE_ERR_ARG, "bad shape");
+    const int oh = (h + 2 * (h & 1) - 2) / 2 + 1, ow = (w + 2 * (w & 1) - 2) / 2 + 1;
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(ew_grid((size_t)planes * oh * ow)), dim3(256), 0, (hipStream_t)stream, in,
+                       out, planes, h, w, oh, ow);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_msssim_level(const float *x, const float *y, int planes, int h, int w, const float *window11, double *ssim_cs,
+                     double *workspace, size_t workspace_elems, void *stream) {
+    if (!x || !y || !window11 || !ssim_cs || !workspace) return fail(CAE_ERR_ARG, "NULL argument");
+    if (planes < 1 || planes > 65535) return fail(CAE_ERR_ARG, "bad plane count");
+    if (h < 11 || w < 11) return fail(CAE_ERR_ARG, "image smaller than the 11-tap window");
+    const int oh = h - 10, ow = w - 10;
+    const int bxr = (ow + 31) / 32, bpp = bxr * ((oh + 31) / 32);
+    if (workspace_elems < (size_t)planes * bpp * 2)
+        return fail(CAE_ERR_ARG, "workspace too small: %zu doubles needed", (size_t)planes * bpp * 2);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(msssim_level_kernel, dim3(bpp, planes), dim3(256), 0, st, x, y, h, w, bxr, bpp, window11, workspace);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(msssim_reduce_kernel, dim3(planes), dim3(256), 0, st, workspace, bpp, (double)oh * ow, ssim_cs);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
 int cae_model_set_profiling(cae_model_t *mm, int enable) {
     Model *m = reinterpret_cast<Model *>(mm);
     if (!m) return fail(CAE_ERR_ARG, "NULL model");

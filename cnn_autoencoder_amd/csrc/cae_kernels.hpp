@@ -1177,6 +1177,143 @@ tile_delta_e_kernel(const uint8_t *a, const uint8_t *b, size_t pixels, int block
     if (threadIdx.x == 0) part[(size_t)tile * blocks_per_tile + blockIdx.x] = red[0];
 }
 
+// ---- MS-SSIM building blocks (pytorch_msssim.ms_ssim as the reference's harness calls it, test_cae.py:47-52):
+// planar float32 images, 11-tap Gaussian window (sigma 1.5) applied separably without padding, K = (0.01, 0.03),
+// data range 255; per level the means of the ssim map and of the contrast-structure map; 2x2 average pooling
+// (zero padding of odd sizes, padded samples counted) between levels.
+static __global__ void u8hwc_to_planes_kernel(const uint8_t *in, float *out, int N, int H, int W, int C) {
+    const size_t total = (size_t)N * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i % ((size_t)H * W);
+        const size_t nc = i / ((size_t)H * W);
+        const int c = (int)(nc % C);
+        const size_t n = nc / C;
+        out[i] = (float)in[(n * H * W + pix) * C + c];
+    }
+}
+
+static __global__ void avgpool2_kernel(const float *in, float *out, int planes, int H, int W, int OH, int OW) {
+    const int ph = H & 1, pw = W & 1;
+    const size_t total = (size_t)planes * OH * OW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+        const size_t pl = i / ((size_t)OW * OH);
+        float s = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int y = 2 * oy - ph + dy, x = 2 * ox - pw + dx;
+                if (y >= 0 && y < H && x >= 0 && x < W) s += in[(pl * H + y) * W + x];
+            }
+        out[i] = s * 0.25f;
+    }
+}
+
+// one block = 32x32 outputs of one plane; part[(plane * bpp + blk) * 2 + {0: ssim, 1: cs}] = partial sums (float64)
+static __global__ void __launch_bounds__(256)
+msssim_level_kernel(const float *X, const float *Y, int H, int W, int bx_per_row, int bpp, const float *win, double *part) {
+    constexpr int T = 32, WIN = 11, IN = T + WIN - 1;
+    __shared__ float sx[IN][IN + 1], sy[IN][IN + 1];
+    __shared__ float vs[5][T][IN + 1];  // after the vertical pass: [quantity][out row][in col]
+    __shared__ double red[2][256];
+    __shared__ float g[WIN];
+    if (threadIdx.x < WIN) g[threadIdx.x] = win[threadIdx.x];
+    const int plane = blockIdx.y, blk = blockIdx.x;
+    const int by = blk / bx_per_row, bx = blk - by * bx_per_row;
+    const int oy0 = by * T, ox0 = bx * T;
+    const int OH = H - WIN + 1, OW = W - WIN + 1;
+    const float *px = X + (size_t)plane * H * W, *py = Y + (size_t)plane * H * W;
+    for (int i = threadIdx.x; i < IN * IN; i += 256) {
+        const int r = i / IN, x = i - r * IN;
+        const int iy = oy0 + r, ix = ox0 + x;
+        const bool ok = iy < H && ix < W;
+        sx[r][x] = ok ? px[(size_t)iy * W + ix] : 0.f;
+        sy[r][x] = ok ? py[(size_t)iy * W + ix] : 0.f;
+    }
+    __syncthreads();
+    // dimension 2 (rows) first, as pytorch_msssim's gaussian_filter does
+    for (int i = threadIdx.x; i < T * IN; i += 256) {
+        const int y = i / IN, x = i - y * IN;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const float u = sx[y + k][x], v = sy[y + k][x], w = g[k];
+            a0 += w * u;
+            a1 += w * v;
+            a2 += w * (u * u);
+            a3 += w * (v * v);
+            a4 += w * (u * v);
+        }
+        vs[0][y][x] = a0;
+        vs[1][y][x] = a1;
+        vs[2][y][x] = a2;
+        vs[3][y][x] = a3;
+        vs[4][y][x] = a4;
+    }
+    __syncthreads();
+    const float C1 = (0.01f * 255.f) * (0.01f * 255.f), C2 = (0.03f * 255.f) * (0.03f * 255.f);
+    double ssum = 0.0, csum = 0.0;
+    for (int i = threadIdx.x; i < T * T; i += 256) {
+        const int y = i / T, x = i - y * T;
+        if (oy0 + y < OH && ox0 + x < OW) {
+            float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < WIN; ++k)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) m[q] += g[k] * vs[q][y][x + k];
+            const float mu1 = m[0], mu2 = m[1];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = m[2] - mu1_sq, s2 = m[3] - mu2_sq, s12 = m[4] - mu12;
+            const float cs = (2.f * s12 + C2) / (s1 + s2 + C2);
+            const float ss = ((2.f * mu12 + C1) / (mu1_sq + mu2_sq + C1)) * cs;
+            ssum += (double)ss;
+            csum += (double)cs;
+        }
+    }
+    red[0][threadIdx.x] = ssum;
+    red[1][threadIdx.x] = csum;
+    __syncthreads();
+#pragma unroll
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + st];
+            red[1][threadIdx.x] += red[1][threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[((size_t)plane * bpp + blk) * 2 + 0] = red[0][0];
+        part[((size_t)plane * bpp + blk) * 2 + 1] = red[1][0];
+    }
+}
+
+// out[plane * 2 + j] = sum of the block partials (fixed order) / samples
+static __global__ void msssim_reduce_kernel(const double *part, int bpp, double samples, double *out) {
+    __shared__ double red[2][256];
+    const int plane = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < bpp; i += 256) {
+        a += part[((size_t)plane * bpp + i) * 2 + 0];
+        b += part[((size_t)plane * bpp + i) * 2 + 1];
+    }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+#pragma unroll
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + st];
+            red[1][threadIdx.x] += red[1][threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[(size_t)plane * 2 + 0] = red[0][0] / samples;
+        out[(size_t)plane * 2 + 1] = red[1][0] / samples;
+    }
+}
+
 static __global__ void u64_to_f64_kernel(const unsigned long long *in, double *out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (double)in[i];

@@ -183,6 +183,16 @@ int cae_tile_ssim(const uint8_t *a_dev, const uint8_t *b_dev, int n, int h, int 
 int cae_tile_delta_e(const uint8_t *a_dev, const uint8_t *b_dev, int n, size_t pixels, double *delta_dev,
                      double *workspace_dev, size_t workspace_elems, void *stream);
 
+/* Building blocks of pytorch_msssim.ms_ssim(x_r, x, data_range=255) as compute_ms_ssim calls it (test_cae.py:47-52):
+ * uint8 HWC tiles -> planar float32 (n*c planes of h x w); one scale of the index on planar images: ssim_cs_dev[2p] =
+ * mean ssim map, [2p+1] = mean contrast-structure map of plane p (11-tap window `window11_dev` applied separably without
+ * padding, K = (0.01, 0.03), data range 255; workspace 2 * planes * ceil((h-10)/32) * ceil((w-10)/32) doubles); and the
+ * 2x2 average pooling between scales (zero padding of odd sizes, out = floor((s + 2(s%2) - 2)/2) + 1 per side). */
+int cae_u8hwc_to_planes(const uint8_t *tiles_dev, int n, int h, int w, int c, float *planes_dev, void *stream);
+int cae_avgpool2(const float *in_dev, int planes, int h, int w, float *out_dev, void *stream);
+int cae_msssim_level(const float *x_dev, const float *y_dev, int planes, int h, int w, const float *window11_dev,
+                     double *ssim_cs_dev, double *workspace_dev, size_t workspace_elems, void *stream);
+
 /* Blocking device -> pinned-host copy on the DMA engines (hsa_amd_memory_async_copy), for symbols on their way
  * to the host coder.  The caller has already waited for the kernels that produce `src_dev` (event / stream
  * synchronise); safe to call from any host thread.  hipMemcpyAsync is not used because the HIP runtime bundled

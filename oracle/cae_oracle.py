@@ -537,3 +537,38 @@ def delta_cielab_uint8(x: np.ndarray, x_r: np.ndarray) -> float:
 
     d = lab(x) - lab(x_r)
     return float(np.mean(np.sqrt((d * d).sum(-1))))
+
+
+def ms_ssim_uint8(x: np.ndarray, x_r: np.ndarray) -> float:
+    """pytorch_msssim.ms_ssim(x_r, x, data_range=255) of test_cae.py:47-52 for uint8 (H, W, C) images, in torch-CPU
+    float32.  pytorch_msssim is absent ("parity unpinned"): restated from the published implementation -- 11-tap Gaussian
+    window (sigma 1.5) applied separably without padding (rows first), K = (0.01, 0.03), five scales with weights
+    (0.0448, 0.2856, 0.3001, 0.2363, 0.1333), relu of the per-channel cs / ssim means, 2x2 average pooling with
+    padding s % 2 (padded zeros counted) between scales, mean over channels."""
+    X = torch.from_numpy(np.moveaxis(x_r, -1, 0)[None]).float()
+    Y = torch.from_numpy(np.moveaxis(x, -1, 0)[None]).float()
+    C = X.shape[1]
+    assert min(X.shape[-2:]) > (11 - 1) * 2 ** 4
+    coords = torch.arange(11, dtype=torch.float) - 11 // 2
+    g = torch.exp(-(coords ** 2) / (2 * 1.5 ** 2))
+    g = (g / g.sum()).view(1, 1, 1, 11).repeat(C, 1, 1, 1)
+    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+
+    def gauss(t):
+        t = F.conv2d(t, g.transpose(2, 3), groups=C)
+        return F.conv2d(t, g, groups=C)
+
+    weights = torch.tensor([0.0448, 0.2856, 0.3001, 0.2363, 0.1333])
+    mcs = []
+    for lvl in range(5):
+        mu1, mu2 = gauss(X), gauss(Y)
+        s1, s2, s12 = gauss(X * X) - mu1 * mu1, gauss(Y * Y) - mu2 * mu2, gauss(X * Y) - mu1 * mu2
+        cs_map = (2 * s12 + c2) / (s1 + s2 + c2)
+        ssim_map = ((2 * mu1 * mu2 + c1) / (mu1 * mu1 + mu2 * mu2 + c1)) * cs_map
+        ssim_c, cs_c = ssim_map.flatten(2).mean(-1), cs_map.flatten(2).mean(-1)
+        if lvl < 4:
+            mcs.append(torch.relu(cs_c))
+            pad = [s % 2 for s in X.shape[2:]]
+            X, Y = F.avg_pool2d(X, kernel_size=2, padding=pad), F.avg_pool2d(Y, kernel_size=2, padding=pad)
+    vals = torch.stack(mcs + [torch.relu(ssim_c)], dim=0)
+    return float(torch.prod(vals ** weights.view(-1, 1, 1), dim=0).mean())

@@ -400,8 +400,15 @@ def test_metrics_match_the_oracle(cae):
     assert float(metrics.compute_ssim(x=xs, x_r=xs)[0]) == 1.0
     with pytest.raises(ValueError):
         metrics.compute_ssim(x=xs[:, :5], x_r=ys[:, :5])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):  # pytorch_msssim's size requirement
         metrics.metric_fun['ms-ssim'](x=xs, x_r=ys)
+    for shape in ((2, 200, 171, 3), (1, 256, 320, 1)):
+        x = rng.integers(0, 256, shape, dtype=np.uint8)
+        x[0] = synth.histo_tile(shape[1], 5, shape[2])[..., :shape[3]]
+        y = np.clip(x.astype(int) + rng.integers(-25, 26, shape), 0, 255).astype(np.uint8)
+        ms = metrics.metric_fun['ms-ssim'](x=torch.from_numpy(x).cuda(), x_r=torch.from_numpy(y).cuda()).cpu().numpy()
+        # tolerance stated: the oracle is float32 torch-CPU, the kernel sums its float32 maps in float64
+        np.testing.assert_allclose(ms, [O.ms_ssim_uint8(a, b) for a, b in zip(x, y)], rtol=2e-5)
 
 
 def test_validation_objective_matches_cpu_restatement(cae):

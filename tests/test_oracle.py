@@ -189,3 +189,16 @@ def test_delta_cielab_restatement_known_answers():
     red[..., 0] = 255
     # distance red -> black = |Lab(red)| since Lab(black) = 0
     assert O.delta_cielab_uint8(red, np.zeros_like(red)) == pytest.approx(np.sqrt(53.24 ** 2 + 80.09 ** 2 + 67.20 ** 2), abs=0.05)
+
+
+def test_ms_ssim_restatement_properties():
+    """Identical images give exactly 1; the index is symmetric in its arguments and falls as noise grows."""
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, (176, 200, 3), dtype=np.uint8)
+    assert O.ms_ssim_uint8(x, x) == pytest.approx(1.0, abs=1e-6)
+    vals = []
+    for amp in (4, 16, 64):
+        y = np.clip(x.astype(int) + rng.integers(-amp, amp + 1, x.shape), 0, 255).astype(np.uint8)
+        vals.append(O.ms_ssim_uint8(x, y))
+        assert O.ms_ssim_uint8(y, x) == pytest.approx(vals[-1], rel=1e-5)
+    assert 1 > vals[0] > vals[1] > vals[2] > 0
