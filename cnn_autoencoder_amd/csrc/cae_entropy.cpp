@@ -321,7 +321,8 @@ int decode_streams(const EntropyTables &T, const uint8_t *const *bufs, const siz
     return CAE_OK;
 }
 
-// Default size of the coder pool: CAE_CODER_THREADS, else the CPUs this process may run on, capped at 16
+// Default size of the coder pool: CAE_CODER_THREADS, else the CPUs this process may run on (divided among the
+// ranks of the node), capped at 16
 // (one rank per GPU shares the host with the other ranks, and a container's CPU share is usually far below the
 // host's thread count; oversubscribing a 16-CPU share with 256 threads made small-tile batches 4x slower).
 int default_threads() {
@@ -333,6 +334,11 @@ int default_threads() {
         int ncpu = (int)std::thread::hardware_concurrency();
         cpu_set_t set;
         if (sched_getaffinity(0, sizeof(set), &set) == 0) ncpu = std::min(ncpu > 0 ? ncpu : 1 << 20, CPU_COUNT(&set));
+        // one rank per GPU (torch.distributed.run exports LOCAL_WORLD_SIZE): the ranks of a node share its cores,
+        // and every rank runs an encode and a decode pool side by side
+        int local_world = 1;
+        if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, std::atoi(e));
+        if (local_world > 1) ncpu = std::max(4, ncpu / (2 * local_world));
         return std::max(1, std::min(ncpu, 16));
     }();
     return cached;
