@@ -123,6 +123,9 @@ def main():
     ap.add_argument('--precision', choices=['f16x3', 'fp32'], default='f16x3',
                     help='conv/GDN arithmetic: f16x3 = operands split into two f16 halves, 3 f16 MFMAs per product, '
                          'fp32 accumulate (fp32-class accuracy); fp32 = exact v_mfma_f32_32x32x2_f32')
+    ap.add_argument('--rehearse-on-one-gpu', action='store_true',
+                    help='N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and the collective runs on gloo '
+                         '(RCCL refuses two ranks on one device); numbers are meaningless, the code path is the real one')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -134,11 +137,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     os.environ['CAE_PRECISION'] = args.precision
     cfg = dict(synth.CANONICAL)
@@ -176,12 +184,13 @@ def main():
     t0 = time.perf_counter()
     # K steps, software-pipelined: the host range-codes batch k while the GPU runs batch k+1 / k-1
     local_stats, _ = coder.run([tiles_dev] * args.steps)
-    local_stats = local_stats.to(dev)
+    cdev = torch.device('cpu') if args.rehearse_on_one_gpu else dev  # gloo rehearsal: host tensors
+    local_stats = local_stats.to(cdev)
     all_stats = slide.gather_stats(local_stats)  # the one collective of the path (RCCL all_gather)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
