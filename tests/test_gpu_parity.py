@@ -329,6 +329,28 @@ def test_arithmetic_paths_agree_on_large_ragged_tiles(cae, ks, shape):
     assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3
 
 
+@pytest.mark.parametrize('shape', [(5, 5), (6, 9), (16, 16), (17, 33), (33, 17), (64, 5), (8, 130)])
+def test_small_and_thin_tiles_against_the_oracle(cae, shape):
+    """Smallest legal sizes (every level's input >= 2 for the reflect padding) and thin strips, GDN model, both
+    arithmetic paths (parametrised fixture): latents and reconstruction against the CPU oracle."""
+    from oracle import cae_oracle as O
+    from cnn_autoencoder_amd import synth
+    cfg = dict(synth.CANONICAL, channels_net=8, channels_bn=16, compression_level=3)
+    state = synth.synthetic_state(cfg, seed=9)
+    model = cae.autoencoder_from_state_dict(state)
+    h, w = shape
+    tiles = synth.uniform_tiles(2, h, w)
+    x = torch.from_numpy(tiles).permute(0, 3, 1, 2).float() / 255.0
+    y_ref, _ = O.analysis_forward(x, oracle_layers(state, 'encoder'))
+    y = model['encoder'].module.forward_u8(torch.from_numpy(tiles).cuda()).cpu()
+    assert y.shape == y_ref.shape
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=RTOL, atol=ATOL)
+    yq = torch.round(y_ref)
+    x_ref, _ = O.synthesis_forward(yq, oracle_layers(state, 'decoder'))
+    x_r, _ = model['decoder'](yq.cuda())
+    np.testing.assert_allclose(x_r[0].cpu().numpy(), x_ref.numpy(), rtol=RTOL, atol=ATOL * max(1.0, float(x_ref.abs().max())))
+
+
 def test_error_behaviour(cae):
     from cnn_autoencoder_amd import synth
     state = synth.synthetic_state(dict(synth.CANONICAL, channels_net=32, channels_bn=48), seed=2)
