@@ -424,6 +424,16 @@ static int run_stages(Model *m, const Layer &l, bool synthesis, int n, int ch, i
 
 // LDS need of conv_s2_f16_kernel<KS,CT,GDN> (same formula as the kernel's constexprs): two stage buffers of
 // weights + halo.  k=5 with 192 output channels needs 192 KiB: such a layer runs on the fp32 kernel instead.
+// LDS need of deconv_last_f16_kernel (LastGeomF16: <3, 8, 3> and <5, 4, 2>): halo ring + all weights resident.  A last
+// layer with more than 160 input channels does not fit and runs on the generic transposed-convolution kernel.
+static bool last_f16_fits(int ks, int cin) {
+    const int nq = (cin + 31) / 32;
+    const int nb = ks == 3 ? 2 : 3, nw = ks == 3 ? 8 : 4, depth = ks == 3 ? 3 : 2;
+    const int halo_instr = (8 * (nw + nb - 1) * (32 + nb - 1) + 63) / 64;
+    const int stage = ((halo_instr + nw - 1) / nw) * nw * 1024;
+    return depth * stage + nb * nb * nq * 2048 <= 160 * 1024;
+}
+
 static bool conv_f16_fits(int ks, int ct, bool gdn) {
     if (gdn && ct > 4) return false;
     const int halo_instr = (4 * 16 * (2 * 16 + ks - 2) + 63) / 64;
@@ -887,7 +897,7 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
         prof.begin();
         if (f16) {
             a.gp = (const float *)l.gp16;
-            if (last && l.wp_edge16) {
+            if (last && l.wp_edge16 && last_f16_fits(m->ks, l.cin)) {
                 a.wp = (const float *)l.wp_edge16;
                 a.cci = (l.cin + 31) / 32;
                 a.tiles_x = (cw + 31) / 32;
