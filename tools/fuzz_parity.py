@@ -53,6 +53,16 @@ for case in range(n_cases):
             enc.cuda(); dec.cuda()
             y = enc.forward_u8(torch.from_numpy(tiles).cuda()).cpu()
             x_r, _ = dec(yq.cuda())
+            # fused quantiser / dequantiser entry points == the unfused calls, bit for bit
+            eb = cae.EntropyBottleneck(kw['channels_bn']).eval()
+            with torch.no_grad():
+                eb.quantiles[:, 0, 1] += torch.linspace(-0.45, 0.45, kw['channels_bn'])
+            eb.update(force=True)
+            eb.cuda()
+            td = torch.from_numpy(tiles).cuda()
+            sym = enc.forward_u8_symbols(td, eb)
+            assert torch.equal(sym, eb.quantize_symbols(enc.forward_u8(td))), 'fused quantiser differs'
+            assert torch.equal(dec.forward_symbols_u8(sym, eb), dec.forward_u8(eb.dequantize_symbols(sym))), 'fused dequantiser differs'
             enc.cpu(); dec.cpu()
         except Exception as e:
             fails += 1
