@@ -1,5 +1,5 @@
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import cae_oracle as O
 from cnn_autoencoder_amd import metrics
 rng = np.random.default_rng(5); fails = 0

@@ -4,7 +4,7 @@ residual, batch norm, expansion) and tile sizes against the CPU oracle / torch-C
 usage: fuzz_parity.py [n_cases] [seed]   -> prints failures, exits 1 if any."""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import cnn_autoencoder_amd as cae

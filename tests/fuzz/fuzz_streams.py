@@ -4,7 +4,7 @@ random batch counts, ragged batch sizes, tile sizes and pipeline depths must rep
 decompress() / tile_sse() exactly.  usage: fuzz_streams.py [n_cases] [seed]"""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cnn_autoencoder_amd as cae
 from cnn_autoencoder_amd import slide, synth
 
