@@ -98,7 +98,7 @@ class SlideCoder:
         self.depth = 3  # batches the analysis runs ahead of the synthesis in run()
         self._pinned = {}
         self._busy = {}  # pinned buffer key -> event of the asynchronous copy that is still reading it
-        self._copy_stream = None
+        self._copy_stream = None  # side stream of the H2D copies
         self.timers = {}
 
     # ---- simple (unpipelined) entry points ---------------------------------------------------
@@ -158,6 +158,11 @@ class SlideCoder:
         self._busy[key] = ev
         return dev, ev
 
+    def _h2d_stream(self):
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(_dev())
+        return self._copy_stream
+
     def _wait_free(self, key):
         ev = self._busy.pop(key, None)
         if ev is not None:
@@ -171,9 +176,7 @@ class SlideCoder:
         from concurrent.futures import ThreadPoolExecutor
         from . import _lib
         main = torch.cuda.current_stream(_dev())
-        if self._copy_stream is None:
-            self._copy_stream = (torch.cuda.Stream(_dev()), torch.cuda.Stream(_dev()))
-        up = self._copy_stream[1]
+        up = self._h2d_stream()
         depth = self.depth
 
         def stage(k, batch):
@@ -216,9 +219,7 @@ class SlideCoder:
         from concurrent.futures import ThreadPoolExecutor
         from . import _lib
         main = torch.cuda.current_stream(_dev())
-        if self._copy_stream is None:
-            self._copy_stream = (torch.cuda.Stream(_dev()), torch.cuda.Stream(_dev()))
-        up = self._copy_stream[1]
+        up = self._h2d_stream()
         depth = self.depth
         lh, lw = h // 2 ** self.level, w // 2 ** self.level
         C = self.eb.channels
@@ -289,11 +290,7 @@ class SlideCoder:
         from . import _lib
         dev = batches[0].device
         main = torch.cuda.current_stream(dev)
-        if self._copy_stream is None:
-            # one side stream per direction: a D2H queued behind a not-yet-finished analysis must not hold
-            # back the H2D the next synthesis is waiting for
-            self._copy_stream = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-        copy, copy_up = self._copy_stream
+        copy_up = self._h2d_stream()  # H2D beside the kernels of the main stream; D2H runs on the DMA engines (HSA)
         K = len(batches)
         # analysis runs DEPTH batches ahead of synthesis: the host always has a batch to code, and the GPU has analysis
         # work while the first batch crosses the host (D2H + encode + decode + H2D ~ 1.8 steps)

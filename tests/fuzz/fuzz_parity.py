@@ -75,6 +75,8 @@ for case in range(n_cases):
     ex = float((x_r[0].cpu() - xr_ref).abs().max() / max(1.0, float(xr_ref.abs().max())))
     assert all((t is None) != kw['multiscale_analysis'] for t in x_r[1:])  # colour layers only with multiscale_analysis
     ok = y.shape == y_ref.shape and ey < 1e-4 and ex < 1e-4
+    if case % 100 == 99:
+        print(f'... {case + 1} cases, {fails} failures so far, {time.time() - t_start:.0f} s', flush=True)
     if not ok:
         fails += 1
         print('FAIL', case, prec, kw, (n, h, w), 'err', ey, ex)
