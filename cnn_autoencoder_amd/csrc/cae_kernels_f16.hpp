@@ -223,12 +223,18 @@ __global__ void __launch_bounds__(256, 1) conv_s2_f16_kernel(const LayerArgs p) 
     auto issue_stage = [&](int q, auto ky_tag, char *buf) {
         constexpr int ky = decltype(ky_tag)::value;
         const char *wsrc = (const char *)p.wp + (size_t)(q * KS + ky) * W_BYTES;
+#ifdef CAE_EXP_F16C_NOWDMA  // timing-only ablation: weights staged for stage 0 only (wrong results)
+        if (q == 0 && ky == 0)
+#endif
 #pragma unroll
         for (int i = 0; i < (W_INSTR + NW - 1) / NW; ++i) {
             const int j = wave + i * NW;
             if (j < W_INSTR) glds16(wsrc + j * 1024 + woff, buf + j * 1024);
         }
         const char *planes = in_n + (size_t)(2 * q) * plane_bytes;
+#ifdef CAE_EXP_F16C_NOHDMA  // timing-only ablation: halo staged for stage 0 only (wrong results)
+        if (q == 0 && ky == 0)
+#endif
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             const int j = wave + i * NW;
