@@ -169,13 +169,19 @@ __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const L
 
 // =================================================================================================
 // conv_s2_f16_kernel: strided reflect conv (+bias) (+GDN), f16x3, C8S in.
-//   block tile = 16 x 16 output pixels (wave w: rows 4w..4w+3; column tile pt: rows 4w+2pt, +1)
+//   block tile = 16 x 16 output pixels, NW waves x PT = 8 / NW column tiles of 2 rows x 16 pixels
+//   (wave w: rows 2 PT w .. 2 PT w + 2 PT - 1; column tile pt: rows 2 PT w + 2 pt, +1)
 //   stage = (16-channel chunk q, kernel row ky):
 //     weights [kx][ct][hl][64][8 f16]  (KS*CT*2 KiB)   +   halo [pl][hl][16 rows][WH][16 B]
 // =================================================================================================
+// waves per block: 8 waves x 1 column tile (two waves per SIMD cover each other's operand waits) measured 4-8 % (conv2),
+// 2-4 % (conv3), 17 % (conv4) faster than 4 waves x 2 column tiles at the same staging traffic (r01_experiments.md)
+#ifndef CAE_CONV_F16_NW
+#define CAE_CONV_F16_NW 8
+#endif
 template <int KS, int CT, bool GDN>
-__global__ void __launch_bounds__(256, 1) conv_s2_f16_kernel(const LayerArgs p) {
-    constexpr int NW = 4, PT = 2;
+__global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(const LayerArgs p) {
+    constexpr int NW = CAE_CONV_F16_NW, PT = 8 / NW;  // 8 waves x 1 column tile (shipped) | 4 waves x 2
     constexpr int PAD = KS / 2;
     constexpr int TX = 16, TY = 16;
     constexpr int WH = 2 * TX + KS - 2;
@@ -247,7 +253,7 @@ __global__ void __launch_bounds__(256, 1) conv_s2_f16_kernel(const LayerArgs p) 
     for (int pt = 0; pt < PT; ++pt) init_acc<CT>(acc[pt], p.bias, h, 0.0f);
 
     // B operand of (column tile pt, tap kx): halo [pl = h][hl][row 4w + 2pt + (m>>4)][2(m&15) + kx]
-    const int b_off = W_BYTES + (((2 * h) * TY + 4 * wave + (m >> 4)) * WH + 2 * (m & 15)) * 16;
+    const int b_off = W_BYTES + (((2 * h) * TY + 2 * PT * wave + (m >> 4)) * WH + 2 * (m & 15)) * 16;
     constexpr int B_HL = PLANE_PIECES * 16;  // hi -> lo
     constexpr int B_PT = 2 * WH * 16;        // column tile 0 -> 1 (two rows down)
     int sc = 0;
@@ -307,7 +313,7 @@ __global__ void __launch_bounds__(256, 1) conv_s2_f16_kernel(const LayerArgs p) 
     }
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-        const int oy = oy0 + 4 * wave + 2 * pt + (m >> 4), ox = ox0 + (m & 15);
+        const int oy = oy0 + 2 * PT * wave + 2 * pt + (m >> 4), ox = ox0 + (m & 15);
         store_tiles_f16<CT>(acc[pt], p, n, oy, ox, h, oy < p.OH && ox < p.OW);
     }
 }

@@ -7,7 +7,7 @@
 namespace cae {
 template <int KS, int CT, bool GDN>
 static int launch_conv_f16_t(const LayerArgs &a, hipStream_t st) {
-    constexpr int NW = 4;
+    constexpr int NW = CAE_CONV_F16_NW;
     constexpr int WH = 2 * 16 + KS - 2;
     constexpr int HALO_INSTR = (4 * 16 * WH + 63) / 64;
     constexpr int CONV_STAGE = KS * CT * 2 * 1024 + HALO_INSTR * 1024;
