@@ -34,6 +34,10 @@ SYMBOLS = {
     'cae_model_set_layer': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cae_model_set_layer_act': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_model_set_precision': (c_int, [c_void_p, c_int]),
+    'cae_last_range_ticket': (ctypes.c_int64, []),
+    'cae_range_check': (c_int, [c_void_p, ctypes.c_int64, c_void_p]),
+    'cae_thread_force_fp32': (None, [c_int]),
+    'cae_model_effective_precision': (c_int, [c_void_p, c_void_p]),
     'cae_model_set_entropy': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cae_analysis': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_synthesis': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),

@@ -6,6 +6,7 @@
 #include "cae_launch.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -13,6 +14,8 @@
 namespace cae {
 
 thread_local std::string g_last_error;
+thread_local int64_t g_last_ticket = 0;  // range ticket of this thread's latest analysis / synthesis call (0: fp32 call)
+thread_local int g_force_fp32 = 0;       // cae_thread_force_fp32
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -115,6 +118,13 @@ static std::vector<float> pack_last(const float *w, int cin, int cout, int ks) {
 static inline void split_half(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
+}
+
+// every entry representable in the split format (finite, |v| <= 65504)?
+static bool fits_f16(const float *v, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        if (!(std::fabs(v[i]) <= 65504.0f)) return false;
+    return true;
 }
 
 // weights -> [q][ky][kx][ct][hl][lane][8]: W(cout = 32ct + (lane&31), cin = 16q + 8(lane>>5) + j, ky, kx)
@@ -257,7 +267,28 @@ int Model::ensure_device() {
         if (rc) return rc;
         density_dirty = false;
     }
+    if (!flags) {
+        HIP_TRY(hipHostMalloc((void **)&flags, kFlagSlots * sizeof(int), hipHostMallocMapped));
+        memset(flags, 0, kFlagSlots * sizeof(int));
+        HIP_TRY(hipHostGetDevicePointer((void **)&flags_dev, flags, 0));
+    }
     return CAE_OK;
+}
+
+int *Model::next_flag(int64_t *ticket) {
+    *ticket = ++flag_seq;
+    const int slot = (int)(*ticket % kFlagSlots);
+    *(volatile int *)(flags + slot) = 0;  // the word's previous user was kFlagSlots calls ago
+    g_last_ticket = *ticket;
+    return flags_dev + slot;
+}
+
+bool Model::f16_usable() const {
+    if (precision != 1 || g_force_fp32) return false;
+    for (auto *tr : {&enc, &dec})
+        for (auto &l : *tr)
+            if (l.set && l.f16_bad) return false;
+    return true;
 }
 
 static void free_stages(Layer &l) {
@@ -287,6 +318,7 @@ Model::~Model() {
     for (int i = 0; i < 2; ++i)
         if (ws16[i]) (void)hipFree(ws16[i]);
     if (zero) (void)hipFree(zero);
+    if (flags) (void)hipHostFree(flags);
     if (medians_dev) (void)hipFree(medians_dev);
     if (density_dev) (void)hipFree(density_dev);
     if (bits_ws) (void)hipFree(bits_ws);
@@ -512,7 +544,11 @@ int cae_model_set_layer(cae_model_t *mm, int track, int index, int cin, int cout
     } else if (track == CAE_SYNTHESIS && index == m->L - 1 && cout <= 4 && beta == nullptr) {
         if ((rc = upload(pack_last(w, cin, cout, m->ks), &l.wp_edge))) return rc;
     }
+    l.f16_bad = false;
     if (m->precision == 1) {
+        // the split format holds |v| <= 65504: a model with larger (or non-finite) weights runs on the fp32 kernels
+        const size_t nw = (size_t)cin * cout * m->ks * m->ks;
+        l.f16_bad = !fits_f16(w, nw) || (gamma && !fits_f16(gamma, (size_t)cout * cout));
         if (l.wp_edge16) {
             (void)hipFree(l.wp_edge16);
             l.wp_edge16 = nullptr;
@@ -614,6 +650,31 @@ int cae_model_set_precision(cae_model_t *mm, int precision) {
     return CAE_OK;
 }
 
+int64_t cae_last_range_ticket(void) { return g_last_ticket; }
+
+void cae_thread_force_fp32(int on) { g_force_fp32 = on != 0; }
+
+int cae_range_check(cae_model_t *mm, int64_t ticket, int *overflowed) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !overflowed) return fail(CAE_ERR_ARG, "NULL argument");
+    *overflowed = 0;
+    if (ticket == 0) return CAE_OK;  // an fp32 call: nothing to check
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (ticket < 0 || ticket > m->flag_seq || !m->flags) return fail(CAE_ERR_ARG, "unknown range ticket");
+    if (m->flag_seq - ticket >= Model::kFlagSlots)
+        return fail(CAE_ERR_ARG, "range ticket too old (%d calls are tracked)", Model::kFlagSlots);
+    *overflowed = *(volatile int *)(m->flags + ticket % Model::kFlagSlots) != 0;
+    return CAE_OK;
+}
+
+int cae_model_effective_precision(cae_model_t *mm, int *precision) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m || !precision) return fail(CAE_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    *precision = m->f16_usable() ? 1 : 0;
+    return CAE_OK;
+}
+
 int cae_model_set_entropy(cae_model_t *mm, int channels, int cdf_stride, const int32_t *cdf, const int32_t *cdf_length,
                           const int32_t *offset, const float *medians) {
     Model *m = reinterpret_cast<Model *>(mm);
@@ -660,8 +721,11 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
     std::lock_guard<std::mutex> lk(m->mu);
     int rc;
     if ((rc = m->ensure_device())) return rc;
-    const bool f16 = m->precision == 1;
+    const bool f16 = m->f16_usable();
     const bool first_fused = f16 ? m->enc[0].wp_edge16 != nullptr : m->enc[0].wp_edge != nullptr;
+    int64_t ticket = 0;
+    g_last_ticket = 0;
+    int *flag = f16 ? m->next_flag(&ticket) : m->flags_dev;  // (fp32 kernels never write it)
 
     // workspace: ws[0] = converted input, ws[1]/ws[2] ping-pong.  fp32 C8 and split C8S records are
     // both 32 B per (plane, pixel), so the same buffers serve either precision.
@@ -698,10 +762,10 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
                 hipLaunchKernelGGL(u8hwc_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint8_t *)tiles,
                                    (float *)m->ws[1], n, h, w, m->c_org, p0);
                 hipLaunchKernelGGL(c8_to_c8s_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)m->ws[1],
-                                   (char *)m->ws[0], (size_t)n * p0 * h, w);
+                                   (char *)m->ws[0], (size_t)n * p0 * h, w, flag);
             } else {
                 hipLaunchKernelGGL(nchw_to_c8s_kernel<false>, dim3(ew_grid(tot)), dim3(256), 0, st,
-                                   (const float *)tiles, (char *)m->ws[0], n, m->c_org, h, w, p0);
+                                   (const float *)tiles, (char *)m->ws[0], n, m->c_org, h, w, p0, flag);
             }
         } else if (fmt == CAE_FMT_U8_HWC) {
             hipLaunchKernelGGL(u8hwc_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint8_t *)tiles,
@@ -732,6 +796,7 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
         a.beta = l.beta;
         a.zero = m->zero;
         a.medians = m->zero;
+        a.flag = flag;
         a.N = n;
         a.H = ch;
         a.W = cw;
@@ -777,7 +842,7 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
             if (!last) {
                 const size_t orows = (size_t)n * l.ct * 4 * a.OH;
                 hipLaunchKernelGGL(c8_to_c8s_kernel, dim3(ew_grid(orows * a.OW)), dim3(256), 0, st, (const float *)a.out,
-                                   (char *)final_out, orows, a.OW);
+                                   (char *)final_out, orows, a.OW, flag);
                 HIP_TRY(hipGetLastError());
                 a.out = final_out;
             }
@@ -828,7 +893,10 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
     std::lock_guard<std::mutex> lk(m->mu);
     int rc;
     if ((rc = m->ensure_device())) return rc;
-    const bool f16 = m->precision == 1;
+    const bool f16 = m->f16_usable();
+    int64_t ticket = 0;
+    g_last_ticket = 0;
+    int *flag = f16 ? m->next_flag(&ticket) : m->flags_dev;
 
     // planes of the converted latents: padded so whole MFMA k-steps can be read (zero channels)
     const int p0 = f16 ? 4 * ((m->c_bn + 31) / 32) : (m->c_bn + 7) / 8;
@@ -857,7 +925,7 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
     const size_t tot = (size_t)n * p0 * lh * lw;
     if (f16)
         hipLaunchKernelGGL(nchw_to_c8s_kernel<true>, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (char *)m->ws[0], n,
-                           m->c_bn, lh, lw, p0, symbols, (const float *)m->medians_dev);
+                           m->c_bn, lh, lw, p0, flag, symbols, (const float *)m->medians_dev);
     else
         hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, latents, (float *)m->ws[0], n,
                            m->c_bn, lh * lw, p0, symbols, (const float *)m->medians_dev);
@@ -882,6 +950,7 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
         a.beta = l.beta;
         a.zero = m->zero;
         a.medians = m->zero;
+        a.flag = flag;
         a.N = n;
         a.H = ch;
         a.W = cw;

@@ -39,6 +39,7 @@ struct Layer {
     void *wp16 = nullptr;      // f16x3 path: packed hi/lo weights
     void *gp16 = nullptr;      // f16x3 path: packed hi/lo gamma
     void *wp_edge16 = nullptr; // f16x3 path: packed weights of the first-conv / last-deconv kernel
+    bool f16_bad = false;      // a weight / gamma entry is not finite in f16: the model runs on the fp32 kernels
 };
 
 // Integer tables of the factorized entropy model + per-row encoder constants.
@@ -84,6 +85,13 @@ struct Model {
     size_t ws16_bytes[2] = {0, 0};
     bool profiling = false;
     std::vector<std::vector<std::pair<void *, void *>>> prof[2];
+    // f16x3 range guard: ring of overflow words in pinned host memory (device-visible), one per call (ticket % kFlagSlots)
+    static constexpr int kFlagSlots = 1024;
+    int *flags = nullptr;      // host view
+    int *flags_dev = nullptr;  // device view of the same words
+    int64_t flag_seq = 0;
+    int *next_flag(int64_t *ticket);  // takes a ticket, clears its word, remembers it as this thread's last ticket
+    bool f16_usable() const;
     int ensure_ws(int which, size_t bytes);
     int ensure_device();
     ~Model();

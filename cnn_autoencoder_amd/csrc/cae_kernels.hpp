@@ -56,7 +56,17 @@ struct LayerArgs {
     int res_planes;     // planes of `res` (the unit input may carry fewer padded planes than the output)
     int post_act;       // activation after the residual sum
     const float *medians;  // >= 192 floats: per-channel medians (OUT_SYM, fused quantiser) or zeros; never null
+    int *flag;          // f16x3 range guard: set to 1 when a value leaves the f16 range (never null on the f16x3 path)
 };
+
+// NaN-safe float -> integer epilogues (a NaN / out-of-range cast is undefined behaviour): v_max / v_min return the
+// non-NaN operand, so a NaN becomes 255 (uint8) or the lower clamp (symbols; the coder then rejects the value)
+__device__ __forceinline__ uint8_t clip_u8(float q) {
+    return (uint8_t)__builtin_fmaxf(__builtin_fminf(q, 255.0f), 0.0f);
+}
+__device__ __forceinline__ int round_sym(float d) {
+    return (int)rintf(__builtin_fminf(__builtin_fmaxf(d, -1073741824.0f), 1073741824.0f));
+}
 
 // compile-time unrolled loop: f(std::integral_constant<int, I>{}) for I = 0..N-1
 template <int N, class F, int... I>
@@ -215,16 +225,14 @@ __device__ __forceinline__ void store_tiles_impl(const f32x16 (&acc)[CT], const 
                 if (c < p.cout) {
                     const float v = ACT ? apply_act(acc[ct][r], p.act) : acc[ct][r];
                     if (fmt == OUT_U8HWC) {  // x*255 -> clip(0,255) -> truncating cast  (_autoencoders.py:576-580)
-                        float q = v * 255.0f;
-                        q = q < 0.0f ? 0.0f : (q > 255.0f ? 255.0f : q);
-                        ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + c] = (uint8_t)q;
+                        ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + c] = clip_u8(v * 255.0f);
                     } else {
                         // OUT_SYM: symbols = int(round_half_even(y - median_c)), stored through the same float store
                         // (bit pattern); p.medians points at zeros for OUT_NCHW (never null), so both formats share one code path.
                         // (A separate int32 store path made the compiler keep the accumulators in scratch memory.)
                         const size_t off = (((size_t)n * p.cout + c) * p.OH + oy) * p.OW + ox;
                         const float d = v - p.medians[c];
-                        ((float *)p.out)[off] = fmt == OUT_SYM ? __int_as_float((int)rintf(d)) : d;
+                        ((float *)p.out)[off] = fmt == OUT_SYM ? __int_as_float(round_sym(d)) : d;
                     }
                 }
             });
@@ -764,9 +772,7 @@ __global__ void __launch_bounds__(NW * 64, 2) deconv_last_kernel(const LayerArgs
                 for (int r = 0; r < 4; ++r) {
                     const int oy = 2 * iy + (r >> 1), ox = 2 * ix + (r & 1);
                     if (p.outfmt == OUT_U8HWC) {
-                        float v = acc[t][r] * 255.0f;
-                        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
-                        ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + g] = (uint8_t)v;
+                        ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + g] = clip_u8(acc[t][r] * 255.0f);
                     } else {
                         ((float *)p.out)[(((size_t)n * p.cout + g) * p.OH + oy) * p.OW + ox] = acc[t][r];
                     }
@@ -877,7 +883,7 @@ static __global__ void c8_to_nchw_kernel(const float *in, float *out, int N, int
 static __global__ void quantize_kernel(const float *y, const float *medians, int32_t *sym, int C, int HW, size_t total) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)((i / HW) % C);
-        sym[i] = (int32_t)rintf(y[i] - medians[c]);
+        sym[i] = round_sym(y[i] - medians[c]);
     }
 }
 
@@ -901,7 +907,7 @@ quantize_export4_kernel(const float *y, const float *medians, int32_t *sym, int 
                 const float med = medians[(i / HW4) % C];
                 i32x4 q;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q[e] = (int32_t)rintf(v[k][e] - med);
+                for (int e = 0; e < 4; ++e) q[e] = round_sym(v[k][e] - med);
                 ((i32x4 *)sym)[i] = q;
             }
         }

@@ -30,6 +30,33 @@ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
+// ---- range guard ---------------------------------------------------------------------------------------
+// f16 carries 5 exponent bits: a value above F16_MAX cannot be stored in the split format (hi = inf).  Every
+// kernel that writes split rows raises *flag when that happens; the host side then repeats the call on the exact-fp32
+// kernels (cae_range_check, include/cae_hip.h).  Values are finite by induction (finite weights checked on upload,
+// finite inputs checked here), so a maximum is enough to see an overflow.
+constexpr float F16_MAX = 65504.0f;
+
+__device__ __forceinline__ void raise_if_over(float mx, int *flag) {
+    if (!(mx <= F16_MAX)) *flag = 1;  // (negated compare: a NaN raises too)
+}
+
+// Per-pixel power-of-two scale for the GDN squares: the squares of a pixel's channels are formed from y * sc with
+// sc = 2^-e chosen so that the pixel's largest |y * sc| lies in [64, 128): (y sc)^2 <= 2^14 fits f16 whatever the
+// magnitude of y (unscaled squares overflowed at |y| > 255.9), and squares of small activations no longer fall
+// into the f16 subnormals.  beta enters the norm accumulator as beta * sc^2 and the result is multiplied by
+// 1 / sc^2: every factor is a power of two, so apart from the range the arithmetic is unchanged.  A pixel is one MFMA
+// column (lanes l and l + 32), the contraction runs over rows: a per-column scale commutes with it.
+// -> sc (this lane's pixel); *isc = 1 / sc.  The exponent is clamped to +-60 so sc^2 and 1 / sc^2 stay normal fp32.
+__device__ __forceinline__ float pixel_scale(float mx, float *isc) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    mx = __builtin_fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // both lanes of the pixel
+    int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 127 - 6;          // mx * 2^-e in [64, 128)
+    e = mx > 0.0f ? (e < -60 ? -60 : (e > 60 ? 60 : e)) : 0;
+    *isc = __uint_as_float((unsigned)(127 + e) << 23);
+    return __uint_as_float((unsigned)(127 - e) << 23);
+}
+
 __device__ __forceinline__ f32x16 mfma3(const f16x8 &ah, const f16x8 &al, const f16x8 &bh, const f16x8 &bl,
                                         f32x16 acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
@@ -50,8 +77,23 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&yy)[PTA][CT], const Laye
     const int h = lane >> 5;
     f32x16(&y)[PTA][CT] = yy;
     f32x16 nrm[PT][CT];
+    float psc[PT], pisc[PT];
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) init_acc<CT>(nrm[pt], p.beta, h, 1.0f);
+    for (int pt = 0; pt < PT; ++pt) {
+        float mx = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2)
+                mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(y[PT0 + pt][ct][r]), __builtin_fabsf(y[PT0 + pt][ct][r + 1])));
+        psc[pt] = pixel_scale(mx, &pisc[pt]);
+        init_acc<CT>(nrm[pt], p.beta, h, 1.0f);
+        const float sc2 = psc[pt] * psc[pt];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nrm[pt][ct][r] *= sc2;
+    }
 #pragma unroll
     for (int jt = 0; jt < CT; ++jt) {
         wait_vm0();
@@ -76,7 +118,7 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&yy)[PTA][CT], const Laye
             for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v = y[PT0 + pt][jt][8 * s + e];
+                    const float v = y[PT0 + pt][jt][8 * s + e] * psc[pt];
                     _Float16 a, b;
                     split_f16(v * v, a, b);
                     sh[pt][e] = a;
@@ -93,14 +135,16 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&yy)[PTA][CT], const Laye
         ++sc;
     }
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt)
+    for (int pt = 0; pt < PT; ++pt) {
+        const float back = INVERSE ? pisc[pt] : psc[pt];  // sqrt(n / sc^2) = sqrt(n) / sc,  rsqrt(n / sc^2) = rsqrt(n) sc
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float nv = nrm[pt][ct][r];
-                y[PT0 + pt][ct][r] *= INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv);
+                y[PT0 + pt][ct][r] *= (INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv)) * back;
             }
+    }
 }
 
 // ---- row layouts of the split format ------------------------------------------------------------------
@@ -136,6 +180,13 @@ __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const L
         // v_permlane32_swap per dword leaves the lower lane with [H(ch 0-3) | H(ch 4-7)] and the upper
         // lane with [L(ch 0-3) | L(ch 4-7)]: one 16-byte store per lane and plane instead of two 8-byte.
         char *out = (char *)p.out;
+        float mx = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2)
+                mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(acc[ct][r]), __builtin_fabsf(acc[ct][r + 1])));
+        raise_if_over(mx, p.flag);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -323,10 +374,18 @@ template <int CT, bool INVERSE>
 __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gbuf, const float *beta_lds, int lane) {
     const int h = lane >> 5;
     f32x16 nrm[CT];
+    float mx = 0.0f;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) nrm[ct][r] = beta_lds[32 * ct + acc_row(r) + 4 * h];
+        for (int r = 0; r < 16; r += 2)
+            mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(y[ct][r]), __builtin_fabsf(y[ct][r + 1])));
+    float isc;
+    const float sc = pixel_scale(mx, &isc), sc2 = sc * sc;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nrm[ct][r] = beta_lds[32 * ct + acc_row(r) + 4 * h] * sc2;
 #pragma unroll
     for (int jt = 0; jt < CT; ++jt) {
         const char *gb = gbuf + jt * (CT * 4096) + lane * 16;
@@ -336,7 +395,7 @@ __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gb
             f16x8 sh, sl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = y[jt][8 * s + e];
+                const float v = y[jt][8 * s + e] * sc;
                 _Float16 a, b;
                 split_f16(v * v, a, b);
                 sh[e] = a;
@@ -355,7 +414,7 @@ __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gb
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float nv = nrm[ct][r];
-            y[ct][r] *= INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv);
+            y[ct][r] *= (INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv)) * (INVERSE ? isc : sc);
         }
 }
 
@@ -843,9 +902,7 @@ __global__ void __launch_bounds__(NW * 64, 1) deconv_last_f16_kernel(const Layer
                     for (int r = 0; r < 4; ++r) {
                         const int oy = 2 * iy + (r >> 1), ox = 2 * ix + (r & 1);
                         if (p.outfmt == OUT_U8HWC) {
-                            float v = acc[tt][r] * 255.0f;
-                            v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
-                            ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + g] = (uint8_t)v;
+                            ((uint8_t *)p.out)[(((size_t)n * p.OH + oy) * p.OW + ox) * p.cout + g] = clip_u8(acc[tt][r] * 255.0f);
                         } else {
                             ((float *)p.out)[(((size_t)n * p.cout + g) * p.OH + oy) * p.OW + ox] = acc[tt][r];
                         }
@@ -859,9 +916,10 @@ __global__ void __launch_bounds__(NW * 64, 1) deconv_last_f16_kernel(const Layer
 
 // fp32 NCHW -> split rows (module boundary / latents into the synthesis track); SP: C8SP rows, else C8S
 template <bool SP>
-__global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int H, int W, int planes,
+__global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int H, int W, int planes, int *flag,
                                    const int32_t *sym = nullptr, const float *medians = nullptr) {
     const size_t HW = (size_t)H * W, total = (size_t)N * planes * HW;
+    bool bad = false;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % HW;
         const size_t np = i / HW;
@@ -873,6 +931,7 @@ __global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int
             const int c = plane * 8 + k;
             // sym != nullptr: fused dequantiser (float(sym) + median_c)
             const float v = c < C ? (sym ? (float)sym[(n * C + c) * HW + pix] + medians[c] : in[(n * C + c) * HW + pix]) : 0.0f;
+            bad |= !(__builtin_fabsf(v) <= F16_MAX);
             _Float16 a, b;
             split_f16(v, a, b);
             vh[k] = a;
@@ -882,6 +941,7 @@ __global__ void nchw_to_c8s_kernel(const float *in, char *out, int N, int C, int
         *(f16x8 *)dst = vh;
         *(f16x8 *)(dst + 512) = vl;
     }
+    if (bad) *flag = 1;
 }
 
 // split rows -> fp32 NCHW (bridges)
@@ -900,13 +960,15 @@ __global__ void c8s_to_nchw_kernel(const char *in, float *out, int N, int C, int
 }
 
 // fp32 C8 [rows][W][8] -> C8S rows (more than 4 input channels given as uint8: rare)
-static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t rows, int W) {
+static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t rows, int W, int *flag) {
     const size_t npix = rows * W;
+    float mx = 0.0f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
         const f32x4 a = *(const f32x4 *)(in + i * 8), b = *(const f32x4 *)(in + i * 8 + 4);
         f16x8 vh, vl;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(a[k]), __builtin_fabsf(b[k])));
             _Float16 x, y;
             split_f16(a[k], x, y);
             vh[k] = x;
@@ -919,6 +981,7 @@ static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t rows,
         *(f16x8 *)dst = vh;
         *(f16x8 *)(dst + 512) = vl;
     }
+    raise_if_over(mx, flag);
 }
 
 // C8S rows -> fp32 C8 [rows][W][8] (a layer the f16x3 kernels do not cover runs on the fp32 kernel)

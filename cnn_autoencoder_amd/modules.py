@@ -26,6 +26,32 @@ from .entropy import LowerBound
 REPARAM_OFFSET = 2.0 ** -18
 
 
+class RangeTicket:
+    """Deferred range check of one call on the f16x3 kernels (include/cae_hip.h, "VALID RANGE of f16x3").
+
+    ``overflowed()`` may be asked once the stream work of the call has completed (the caller synchronised with
+    it); ``rerun()`` repeats the call on the exact-fp32 kernels and returns its result."""
+
+    def __init__(self, track, handle, ticket: int, call):
+        self._track, self._handle, self.ticket, self._call = track, handle, int(ticket), call
+
+    def overflowed(self) -> bool:
+        if self.ticket == 0:
+            return False  # the call already ran on the fp32 kernels
+        over = ctypes.c_int(0)
+        _lib.check(_lib.lib().cae_range_check(self._handle.ptr, self.ticket, ctypes.byref(over)))
+        return bool(over.value)
+
+    def rerun(self):
+        self._track.fp32_fallbacks += 1
+        L = _lib.lib()
+        L.cae_thread_force_fp32(1)
+        try:
+            return self._call()
+        finally:
+            L.cae_thread_force_fp32(0)
+
+
 class NonNegativeParametrizer(nn.Module):
     """compressai.ops.parametrizers.NonNegativeParametrizer."""
 
@@ -352,6 +378,7 @@ class _Track(nn.Module):
                       int(kernel_size))
         self._handle: Optional[_lib.Handle] = None
         self._versions = None
+        self.fp32_fallbacks = 0  # calls repeated on the fp32 kernels because a value left the f16 range
         import weakref
         ref = weakref.ref(self)
         for i, unit in enumerate(getattr(self, self._track_attr)):
@@ -380,17 +407,33 @@ class _Track(nn.Module):
         return list(getattr(self, self._track_attr))
 
     def _param_versions(self):
-        # buffers too (BatchNorm running statistics), and the mode: BatchNorm is folded in eval mode only
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers())) + (self.training,)
+        # buffers too (BatchNorm running statistics), the mode (BatchNorm is folded in eval mode only) and the
+        # arithmetic path: changing `precision` / CAE_PRECISION re-packs the layers for the other kernels
+        return (tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+                + (self.training, self.precision_code()))
+
+    def _guarded(self, hd, call, defer: bool = False):
+        """Runs ``call()`` (allocates the outputs, launches, returns them) under the f16x3 range guard: if a value
+        left the f16 range the call is repeated on the fp32 kernels.  ``defer``: no synchronisation here; returns
+        (outputs, RangeTicket) and the caller checks once it has synchronised with the call anyway."""
+        out = call()
+        ticket = RangeTicket(self, hd, _lib.lib().cae_last_range_ticket(), call)
+        if defer:
+            return out, ticket
+        if ticket.ticket:
+            torch.cuda.current_stream().synchronize()
+            if ticket.overflowed():
+                out = ticket.rerun()
+        return out
 
     def _sync(self) -> _lib.Handle:
         _lib.require_gpu()
         if self._handle is None:
             self._handle = _lib.Handle(*self._dims)
-            _lib.check(_lib.lib().cae_model_set_precision(self._handle.ptr, self.precision_code()))
         ver = self._param_versions()
         if ver != self._versions:
             L = _lib.lib()
+            _lib.check(L.cae_model_set_precision(self._handle.ptr, ver[-1]))
             with torch.no_grad():
                 for i, unit in enumerate(self._units()):
                     conv = unit.main
@@ -503,9 +546,12 @@ class Analyzer(_Track):
         dev = _lib.require_gpu()
         hd = self._sync()
         lh, lw = self.latent_size(h, w)
-        y = torch.empty((n, self._dims[2], lh, lw), dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib().cae_analysis(hd.ptr, ptr, fmt, n, h, w, y.data_ptr(), _lib.stream_ptr()))
-        return y
+
+        def call():
+            y = torch.empty((n, self._dims[2], lh, lw), dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().cae_analysis(hd.ptr, ptr, fmt, n, h, w, y.data_ptr(), _lib.stream_ptr()))
+            return y
+        return self._guarded(hd, call)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x (B,C,H,W) float in [0,1] -> y (B,channels_bn,ceil(H/2^L),ceil(W/2^L))."""
@@ -524,10 +570,10 @@ class Analyzer(_Track):
         return self._run(tiles.data_ptr(), _lib.FMT_U8_HWC, tiles.size(0), tiles.size(1), tiles.size(2))
 
 
-    def forward_u8_symbols(self, tiles: torch.Tensor, eb) -> torch.Tensor:
+    def forward_u8_symbols(self, tiles: torch.Tensor, eb, defer: bool = False):
         """tiles (B,H,W,C) uint8 on the GPU -> int32 symbols round(y - median) of `eb` (an EntropyBottleneck):
         analysis with the quantiser fused into the last layer's epilogue (cae_analysis_symbols); equals
-        eb.quantize_symbols(self.forward_u8(tiles))."""
+        eb.quantize_symbols(self.forward_u8(tiles)).  ``defer``: -> (symbols, RangeTicket), see _guarded."""
         dev = _lib.require_gpu()
         if tiles.dim() != 4 or tiles.size(3) != self._dims[0] or tiles.dtype != torch.uint8:
             raise ValueError(f'expected uint8 (B,H,W,{self._dims[0]}), got {tiles.dtype} {tuple(tiles.shape)}')
@@ -537,10 +583,13 @@ class Analyzer(_Track):
         hd = self._sync_entropy(eb)
         n, h, w = tiles.size(0), tiles.size(1), tiles.size(2)
         lh, lw = self.latent_size(h, w)
-        sym = torch.empty((n, self._dims[2], lh, lw), dtype=torch.int32, device=dev)
-        _lib.check(_lib.lib().cae_analysis_symbols(hd.ptr, tiles.data_ptr(), _lib.FMT_U8_HWC, n, h, w, sym.data_ptr(),
-                                                   _lib.stream_ptr()))
-        return sym
+
+        def call():
+            sym = torch.empty((n, self._dims[2], lh, lw), dtype=torch.int32, device=dev)
+            _lib.check(_lib.lib().cae_analysis_symbols(hd.ptr, tiles.data_ptr(), _lib.FMT_U8_HWC, n, h, w,
+                                                       sym.data_ptr(), _lib.stream_ptr()))
+            return sym
+        return self._guarded(hd, call, defer)
 
 
 class NoneColorLayer(nn.Module):
@@ -593,25 +642,28 @@ class Synthesizer(_Track):
         n, _, lh, lw = x.shape
         L = self._dims[3]
         H, W = lh * 2 ** L, lw * 2 ** L
-        if fmt == _lib.FMT_U8_HWC:
-            out = torch.empty((n, H, W, self._dims[0]), dtype=torch.uint8, device=dev)
-        else:
-            out = torch.empty((n, self._dims[0], H, W), dtype=torch.float32, device=dev)
-        brg: List[torch.Tensor] = []
-        brg_ptr = None
-        if bridges and L > 1:
-            brg = [torch.empty((n, u.main.out_channels, lh * 2 ** (i + 1), lw * 2 ** (i + 1)), dtype=torch.float32,
-                               device=dev) for i, u in enumerate(self._units()[:-1])]
-            brg_ptr = (ctypes.c_void_p * (L - 1))(*[b.data_ptr() for b in brg])
-        col: List[torch.Tensor] = []
-        col_ptr = None
-        if colors and self.multiscale_analysis and L > 1:
-            col = [torch.empty((n, self._dims[0], lh * 2 ** (i + 1), lw * 2 ** (i + 1)), dtype=torch.float32,
-                               device=dev) for i in range(L - 1)]
-            col_ptr = (ctypes.c_void_p * (L - 1))(*[c.data_ptr() for c in col])
-        _lib.check(_lib.lib().cae_synthesis_multiscale(hd.ptr, x.data_ptr(), n, lh, lw, out.data_ptr(), fmt, brg_ptr,
-                                                       col_ptr, _lib.stream_ptr()))
-        return out, brg, col
+
+        def call():
+            if fmt == _lib.FMT_U8_HWC:
+                out = torch.empty((n, H, W, self._dims[0]), dtype=torch.uint8, device=dev)
+            else:
+                out = torch.empty((n, self._dims[0], H, W), dtype=torch.float32, device=dev)
+            brg: List[torch.Tensor] = []
+            brg_ptr = None
+            if bridges and L > 1:
+                brg = [torch.empty((n, u.main.out_channels, lh * 2 ** (i + 1), lw * 2 ** (i + 1)),
+                                   dtype=torch.float32, device=dev) for i, u in enumerate(self._units()[:-1])]
+                brg_ptr = (ctypes.c_void_p * (L - 1))(*[b.data_ptr() for b in brg])
+            col: List[torch.Tensor] = []
+            col_ptr = None
+            if colors and self.multiscale_analysis and L > 1:
+                col = [torch.empty((n, self._dims[0], lh * 2 ** (i + 1), lw * 2 ** (i + 1)), dtype=torch.float32,
+                                   device=dev) for i in range(L - 1)]
+                col_ptr = (ctypes.c_void_p * (L - 1))(*[c.data_ptr() for c in col])
+            _lib.check(_lib.lib().cae_synthesis_multiscale(hd.ptr, x.data_ptr(), n, lh, lw, out.data_ptr(), fmt,
+                                                           brg_ptr, col_ptr, _lib.stream_ptr()))
+            return out, brg, col
+        return self._guarded(hd, call)
 
     def forward(self, x: torch.Tensor, bridges: bool = True):
         """y_q (B,channels_bn,h,w) -> (x_r list [full-res, half-res | None, ...], fx_brg list) as the reference:
@@ -625,10 +677,10 @@ class Synthesizer(_Track):
         out, _, _ = self._run(x, _lib.FMT_U8_HWC, False)
         return out
 
-    def forward_symbols_u8(self, sym: torch.Tensor, eb) -> torch.Tensor:
+    def forward_symbols_u8(self, sym: torch.Tensor, eb, defer: bool = False):
         """int32 symbols (B,channels_bn,h,w) on the GPU -> (B,H,W,C) uint8 tiles: the dequantiser of `eb` fused into
         the layout conversion in front of the first layer (cae_synthesis_symbols); equals
-        self.forward_u8(eb.dequantize_symbols(sym))."""
+        self.forward_u8(eb.dequantize_symbols(sym)).  ``defer``: -> (tiles, RangeTicket), see _guarded."""
         dev = _lib.require_gpu()
         if sym.dim() != 4 or sym.size(1) != self._dims[2] or sym.dtype != torch.int32:
             raise ValueError(f'expected int32 (B,{self._dims[2]},h,w), got {sym.dtype} {tuple(sym.shape)}')
@@ -638,7 +690,10 @@ class Synthesizer(_Track):
         hd = self._sync_entropy(eb)
         n, _, lh, lw = sym.shape
         L = self._dims[3]
-        out = torch.empty((n, lh * 2 ** L, lw * 2 ** L, self._dims[0]), dtype=torch.uint8, device=dev)
-        _lib.check(_lib.lib().cae_synthesis_symbols(hd.ptr, sym.data_ptr(), n, lh, lw, out.data_ptr(), _lib.FMT_U8_HWC,
-                                                    _lib.stream_ptr()))
-        return out
+
+        def call():
+            out = torch.empty((n, lh * 2 ** L, lw * 2 ** L, self._dims[0]), dtype=torch.uint8, device=dev)
+            _lib.check(_lib.lib().cae_synthesis_symbols(hd.ptr, sym.data_ptr(), n, lh, lw, out.data_ptr(),
+                                                        _lib.FMT_U8_HWC, _lib.stream_ptr()))
+            return out
+        return self._guarded(hd, call, defer)

@@ -158,6 +158,21 @@ class SlideCoder:
         self._busy[key] = ev
         return dev, ev
 
+    def _redo_analysis(self, t, main):
+        """f16x3 range guard, rare path: the analysis of batch `t` overflowed the f16 range -> repeat it on the fp32
+        kernels.  Runs on the calling (worker) thread but on the MAIN stream, so the handle's workspace is used in
+        stream order; returns the symbols once they are complete."""
+        with torch.cuda.device(t.device), torch.cuda.stream(main):
+            sym = self.enc.forward_u8_symbols(t, self.eb)  # guarded call: falls back to fp32 by itself
+            done = torch.cuda.Event()
+            done.record(main)
+        done.synchronize()
+        return sym
+
+    def _redo_synthesis(self, payloads, h, w, main):
+        with torch.cuda.device(_dev()), torch.cuda.stream(main):
+            return self.decompress(payloads, h, w)  # guarded calls
+
     def _h2d_stream(self):
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(_dev())
@@ -184,16 +199,18 @@ class SlideCoder:
             if ev is not None:
                 main.wait_event(ev)
                 t.record_stream(main)
-            sym = self.enc.forward_u8_symbols(t, self.eb)
+            sym, guard = self.enc.forward_u8_symbols(t, self.eb, defer=True)
             n, C = sym.size(0), sym.size(1)
             hw = sym.numel() // (n * C)
             pin = self._pin(('a', k % (depth + 1)), (n, C, hw), torch.int32)
             ready = torch.cuda.Event()
             ready.record(main)
-            return pin, ready, sym
+            return pin, ready, sym, guard, t
 
-        def pull(pin, ready, sym):  # worker 1: DMA-engine D2H of batch k+1 while worker 2 encodes batch k
+        def pull(pin, ready, sym, guard, t):  # worker 1: DMA-engine D2H of batch k+1 while worker 2 encodes batch k
             ready.synchronize()
+            if guard.overflowed():
+                sym = self._redo_analysis(t, main)
             _lib.check(_lib.lib().cae_copy_to_host(pin.data_ptr(), sym.data_ptr(), sym.numel() * 4))
             return pin
 
@@ -240,35 +257,52 @@ class SlideCoder:
             self._busy[key] = ev
             main.wait_event(ev)
             sym.record_stream(main)
-            return self.dec.forward_symbols_u8(sym.reshape(sym.size(0), C, lh, lw), self.eb)
+            rec, guard = self.dec.forward_symbols_u8(sym.reshape(sym.size(0), C, lh, lw), self.eb, defer=True)
+            done = torch.cuda.Event()
+            done.record(main)
+            return rec, guard, done
 
-        def fetch(j, rec, done):
-            out = self._pin(('o', j % 4), tuple(rec.shape), torch.uint8)
+        def checked(rec, guard, done, payloads):
+            """the reconstruction once it is complete and known to be in range (f16x3 guard; rare fp32 repeat)"""
             done.synchronize()
+            if guard.overflowed():
+                rec = self._redo_synthesis(payloads, h, w, main)
+                torch.cuda.current_stream(rec.device).synchronize()
+            return rec
+
+        def fetch(j, rec, guard, done, payloads):
+            out = self._pin(('o', j % 4), tuple(rec.shape), torch.uint8)
+            rec = checked(rec, guard, done, payloads)
             _lib.check(_lib.lib().cae_copy_to_host(out.data_ptr(), rec.data_ptr(), rec.numel()))
             return out.numpy()
 
         with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=1) as out_pool:
-            inflight, outgoing, j = [], [], 0
+            inflight, outgoing, held, j = [], [], [], 0
 
-            def emit(item):
+            def emit(item, payloads):
                 nonlocal j
-                rec = synth(item)
+                rec, guard, done = synth(item)
                 if not to_host:
-                    return [rec]
-                done = torch.cuda.Event()
-                done.record(main)
-                outgoing.append(out_pool.submit(fetch, j, rec, done))
+                    # one reconstruction is held back: its range check waits for its kernels, which run under the
+                    # next batch's launch work instead of stalling the stream
+                    held.append((rec, guard, done, payloads))
+                    return [checked(*held.pop(0))] if len(held) > 1 else []
+                outgoing.append(out_pool.submit(fetch, j, rec, guard, done, payloads))
                 j += 1
                 # one reconstruction stays in flight: its D2H overlaps the next batch's synthesis
                 return [outgoing.pop(0).result()] if len(outgoing) > 1 else []
 
             for k, payloads in enumerate(payload_batches):
-                inflight.append(pool.submit(decode, k, list(payloads)))
+                payloads = list(payloads)
+                inflight.append((pool.submit(decode, k, payloads), payloads))
                 if len(inflight) > depth:
-                    yield from emit(inflight.pop(0).result())
+                    fut, pl = inflight.pop(0)
+                    yield from emit(fut.result(), pl)
             while inflight:
-                yield from emit(inflight.pop(0).result())
+                fut, pl = inflight.pop(0)
+                yield from emit(fut.result(), pl)
+            while held:
+                yield checked(*held.pop(0))
             while outgoing:
                 yield outgoing.pop(0).result()
 
@@ -307,18 +341,21 @@ class SlideCoder:
 
         def stage_a(k):
             t = batches[k]
-            sym = self.enc.forward_u8_symbols(t, self.eb)  # quantiser fused into the last layer's epilogue
+            # quantiser fused into the last layer's epilogue; range check deferred to the encode worker
+            sym, guard = self.enc.forward_u8_symbols(t, self.eb, defer=True)
             n, C = sym.size(0), sym.size(1)
             hw = sym.numel() // (n * C)
             pin = self._pin(('a', k % (DEPTH + 1)), (n, C, hw), torch.int32)  # in use until encode(k) is done
             ready = torch.cuda.Event()
             ready.record(main)
-            return k, pin, ready, hw, sym
+            return k, pin, ready, hw, sym, guard
 
-        def host_encode(k, pin, ready, hw, sym):
+        def host_encode(k, pin, ready, hw, sym, guard):
             # D2H on the DMA engines from this worker thread (cae_copy_to_host): a hipMemcpyAsync here runs as a
             # blit kernel under PyTorch's HIP runtime and held the main stream up for the whole PCIe transfer
             ready.synchronize()
+            if guard.overflowed():  # f16x3 range guard: repeat this batch on the fp32 kernels
+                sym = self._redo_analysis(batches[k], main)
             _lib.check(_lib.lib().cae_copy_to_host(pin.data_ptr(), sym.data_ptr(), sym.numel() * 4))
             del sym
             t0 = time.perf_counter()
@@ -345,9 +382,9 @@ class SlideCoder:
             sym.record_stream(main)
             lh, lw = h // 2 ** self.level, w // 2 ** self.level
             # dequantiser fused into the layout conversion in front of the first synthesis layer
-            rec = self.dec.forward_symbols_u8(sym.reshape(n, self.eb.channels, lh, lw), self.eb)
+            rec, guard = self.dec.forward_symbols_u8(sym.reshape(n, self.eb.channels, lh, lw), self.eb, defer=True)
             sse = self.tile_sse(rec, t)
-            return sse, [len(p) + 16 for p in payloads], h * w * c
+            return sse, [len(p) + 16 for p in payloads], h * w * c, guard, (k, payloads)
 
         pending = []  # (sse tensor on GPU, nbytes list, samples)
         # two host workers: batch k+1 is range-encoded while batch k is decoded
@@ -370,7 +407,12 @@ class SlideCoder:
                 pending.append(stage_d(k, payloads, back))
                 if keep_payloads:
                     all_payloads.append(payloads)
-        for sse, nbytes, samples in pending:
-            stats_parts.append(tile_stats(nbytes, sse.cpu().tolist(), samples))
+        for sse, nbytes, samples, guard, (k, payloads) in pending:
+            sse_host = sse.cpu().tolist()  # (synchronises with the batch's kernels)
+            if guard.overflowed():  # f16x3 range guard: repeat this batch's synthesis on the fp32 kernels
+                t = batches[k]
+                rec = self._redo_synthesis(payloads, t.shape[1], t.shape[2], main)
+                sse_host = self.tile_sse(rec, t).cpu().tolist()
+            stats_parts.append(tile_stats(nbytes, sse_host, samples))
         self.timers = tm
         return torch.cat(stats_parts), all_payloads

@@ -78,8 +78,28 @@ int cae_model_set_layer_act(cae_model_t *m, int track, int index, int act, const
 /* Arithmetic of the conv / GDN contraction: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32),
  * 1 = "f16x3": every operand split into two f16 halves, three f16 MFMAs per product, fp32
  * accumulate (22 significant bits; same 1e-4 parity bar, ~5x less matrix-pipe time).  Set before
- * cae_model_set_layer.  (No reference counterpart: the reference computes in fp32 on ATen.) */
+ * cae_model_set_layer.  (No reference counterpart: the reference computes in fp32 on ATen,
+ * _autoencoders.py:78-85, :204-211.)
+ *
+ * VALID RANGE of f16x3.  f16 has 5 exponent bits, so the split format holds finite values with
+ * |v| <= 65504 at 22 significant bits (values below 2^-14 keep an absolute accuracy of 2^-25).
+ *   - weights / gamma outside that range: cae_model_set_layer marks the model and every call runs on the
+ *     fp32 kernels (cae_model_effective_precision reports 0);
+ *   - GDN / IGDN squares: formed from y scaled per pixel by a power of two (largest |y| of the pixel's
+ *     channels brought into [64,128)), beta and the result rescaled exactly: any finite pre-GDN magnitude
+ *     is in range; accuracy is 2^-22 relative to the pixel's largest channel;
+ *   - activations between layers, latents into the synthesis track and float inputs: a value with
+ *     |v| > 65504 (or NaN) cannot be stored.  Every kernel that writes the split format then raises the
+ *     call's overflow word, and the results of that call are INVALID.  Protocol: after the call, on the
+ *     same host thread, t = cae_last_range_ticket(); once the stream work of the call has completed
+ *     (stream / event synchronise), cae_range_check(m, t, &over); if over, repeat the call between
+ *     cae_thread_force_fp32(1) / (0): it then runs on the exact-fp32 kernels (fp32 range, as the reference).
+ *     The Python modules do this automatically.  1024 calls per handle are tracked. */
 int cae_model_set_precision(cae_model_t *m, int precision);
+int64_t cae_last_range_ticket(void);         /* thread-local; 0 = the call ran on the fp32 kernels: nothing to check */
+int cae_range_check(cae_model_t *m, int64_t ticket, int *overflowed);
+void cae_thread_force_fp32(int on);          /* thread-local: calls of this thread use the fp32 kernels */
+int cae_model_effective_precision(cae_model_t *m, int *precision);
 
 /* Integer tables of the factorized entropy model, as EntropyBottleneck.update() leaves them
  * (_autoencoders.py:502): quantized_cdf (channels, cdf_stride) int32, cdf_length (channels),
