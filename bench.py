@@ -10,11 +10,23 @@ plus the per-tile rate/distortion record.  Tiles shard over ranks with no data-p
 (weak scaling: the per-GPU batch is fixed); one all_gather of the per-tile statistics closes the
 timed region.  Rank 0 prints ONE JSON line.
 
-Extra objects in the line:
-  roofline      dominant fused kernel (conv/deconv + GDN), algorithmic FLOP / HIP-event time, vs the
-                dense fp32 MFMA peak (the path computes in exact fp32: v_mfma_f32_32x32x2_f32)
+Arithmetic.  Default `f16x3`: every fp32 operand of the conv / GDN contraction is split into two f16
+halves and a product is three v_mfma_f32_32x32x16_f16 (fp32 accumulate, 22 significant bits; range
+guard with fp32 repeat, include/cae_hip.h).  `--precision fp32` = exact v_mfma_f32_32x32x2_f32.
+
+Objects in the line besides the driver's contract:
+  roofline      dominant fused kernel (conv/deconv + GDN).  `achieved` = MFMA FLOP/s the kernel ISSUES
+                (f16x3: 3 per algorithmic FLOP) from the algorithmic FLOP of one launch / its HIP-event time
+                (events recorded by the library around the launch, on the launch stream, inside the timed
+                region); `peak` = dense peak of the instruction issued (f16: 2500, fp32: 157.3 TFLOP/s);
+                `frac` = achieved / peak (<= 1 by construction).  `algorithmic_tflops` and
+                `algorithmic_vs_fp32_mfma_peak` are the same time against the useful fp32 work.
+                `traffic` = HBM bytes per launch from committed rocprofv3 PMC passes (offline; `traffic_source`).
+  fp32_path     (N=1) a short run of the same workload on the exact-fp32 kernels
+  tile256       (N=1) a short run on 256x256x3 tiles, 512 per step
   cpu_baseline  the CPU oracle (torch-CPU conv + restated GDN + C rANS) on a bounded sample of the
-                same workload on this host's cores -- a reported baseline, not the target
+                same tiles on this host's cores -- a reported baseline, not the target
+  parity_vs_cpu the GPU path against that oracle on the very same tiles: bpp, PSNR, bitstreams, pixels
 """
 import argparse
 import json
@@ -29,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak
 
 
 def layer_flops(cfg, h, w):
@@ -58,19 +71,21 @@ def layer_flops(cfg, h, w):
     return enc, dec
 
 
+def oracle_layers(state, part, track):
+    sd, out, i = state[part], [], 0
+    while f'{track}.{i}.model.0.weight' in sd:
+        out.append(dict(weight=sd[f'{track}.{i}.model.0.weight'], bias=sd.get(f'{track}.{i}.model.0.bias'),
+                        beta=sd.get(f'{track}.{i}.model.1.beta'), gamma=sd.get(f'{track}.{i}.model.1.gamma')))
+        i += 1
+    return out
+
+
 def cpu_baseline(state, cfg, tiles, budget_s=20.0):
     """Time the oracle's codec round trip, one tile per call (the reference's call pattern,
-    _autoencoders.py:544), on this host's cores."""
+    _autoencoders.py:544), on this host's cores.  -> (report, per-tile [bytes, sse], payloads, reconstructions)"""
+    import struct
     from oracle import c_oracle as C
     from oracle import cae_oracle as O
-
-    def layers(part, track):
-        sd, out, i = state[part], [], 0
-        while f'{track}.{i}.model.0.weight' in sd:
-            out.append(dict(weight=sd[f'{track}.{i}.model.0.weight'], bias=sd.get(f'{track}.{i}.model.0.bias'),
-                            beta=sd.get(f'{track}.{i}.model.1.beta'), gamma=sd.get(f'{track}.{i}.model.1.gamma')))
-            i += 1
-        return out
 
     # the 1-GPU box shares a 256-thread host: use this job's CPU share (16), not every hardware thread
     try:
@@ -81,11 +96,12 @@ def cpu_baseline(state, cfg, tiles, budget_s=20.0):
     eb = O.EntropyBottleneckOracle(cfg['channels_bn'])
     eb.load(state['fact_ent'])
     eb.update()
-    enc_l, dec_l = layers('encoder', 'analysis_track'), layers('decoder', 'synthesis_track')
-    import struct
+    enc_l = oracle_layers(state, 'encoder', 'analysis_track')
+    dec_l = oracle_layers(state, 'decoder', 'synthesis_track')
     done, t0 = 0, time.perf_counter()
     part = dict(analysis=0.0, entropy_encode=0.0, entropy_decode=0.0, synthesis=0.0)
     L = len(dec_l)
+    per_tile, payloads, recs = [], [], []
     with torch.no_grad():
         for t in tiles:  # O.codec_encode / O.codec_decode, spelled out to time their parts
             h, w, _ = t.shape
@@ -97,18 +113,121 @@ def cpu_baseline(state, cfg, tiles, budget_s=20.0):
             yq = eb.decompress([buf[16:]], (h // 2 ** L, w // 2 ** L), C.rans_decode_with_indexes)
             d = time.perf_counter()
             x_r, _ = O.synthesis_forward(yq, dec_l)
-            O.output_to_tile(x_r[0])
+            rec = O.output_to_tile(x_r[0])
             e = time.perf_counter()
             for k, v in zip(part, (b - a, c - b, d - c, e - d)):
                 part[k] += v
             done += 1
+            per_tile.append((len(buf), float(((rec.astype(np.float64) - t) ** 2).sum())))
+            payloads.append(buf[16:])
+            recs.append(rec)
             if time.perf_counter() - t0 > budget_s:
                 break
     dt = time.perf_counter() - t0
-    return dict(value=done / dt, unit='tiles/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{done} tiles of {tiles[0].shape[0]}x{tiles[0].shape[1]}x{tiles[0].shape[2]}, '
-                       f'encode+decode one tile per call, {dt:.1f} s',
-                ms_per_tile={k: 1e3 * v / done for k, v in part.items()})
+    report = dict(value=done / dt, unit='tiles/s', cores=torch.get_num_threads(), kind='port',
+                  sample=f'{done} tiles of {tiles[0].shape[0]}x{tiles[0].shape[1]}x{tiles[0].shape[2]}, '
+                         f'encode+decode one tile per call, {dt:.1f} s',
+                  ms_per_tile={k: 1e3 * v / done for k, v in part.items()})
+    return report, per_tile, payloads, recs
+
+
+def batch_variants(tiles_dev, n):
+    """n distinct batches from one batch of distinct tiles (flips / transposes on the device): every step codes
+    different data, so the host coder sees fresh symbols instead of one batch replayed."""
+    ops = [lambda t: t, lambda t: t.flip(1), lambda t: t.flip(2), lambda t: t.transpose(1, 2),
+           lambda t: t.flip(1).flip(2), lambda t: t.transpose(1, 2).flip(1), lambda t: t.transpose(1, 2).flip(2),
+           lambda t: t.transpose(1, 2).flip(1).flip(2)]
+    return [ops[i % len(ops)](tiles_dev).contiguous() for i in range(max(1, min(n, len(ops))))]
+
+
+def kernel_table(cfg, H, B, enc_ms, enc_calls, dec_ms, dec_calls, precision):
+    """Per fused kernel: algorithmic FLOP per launch, HIP-event ms per launch, issued MFMA rate and its fraction
+    of the peak of the instruction issued."""
+    enc_fl, dec_fl = layer_flops(cfg, H, H)
+    issue, peak = (3.0, F16_MFMA_PEAK_TFLOPS) if precision == 'f16x3' else (1.0, FP32_MFMA_PEAK_TFLOPS)
+    rows = []
+    for i, f in enumerate(enc_fl):
+        rows.append([f'analysis.{i} conv{"+GDN" if i < len(enc_fl) - 1 else ""}', f * B, enc_ms[1 + i] / max(enc_calls, 1)])
+    for i, f in enumerate(dec_fl):
+        rows.append([f'synthesis.{i} deconv{"+IGDN" if i < len(dec_fl) - 1 else ""}', f * B, dec_ms[1 + i] / max(dec_calls, 1)])
+    out = []
+    for name, flop, ms in rows:
+        alg = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out.append(dict(name=name, ms=ms, flop_per_launch=flop, algorithmic_tflops=alg, issued_tflops=issue * alg,
+                        frac_of_issued_peak=issue * alg / peak))
+    a_ms = sum(enc_ms[1:]) / max(enc_calls, 1)
+    a_alg = sum(enc_fl) * B / (a_ms * 1e-3) / 1e12 if a_ms > 0 else 0.0
+    stack = dict(ms=a_ms, algorithmic_tflops=a_alg, issued_tflops=issue * a_alg, frac_of_issued_peak=issue * a_alg / peak,
+                 algorithmic_vs_fp32_mfma_peak=a_alg / FP32_MFMA_PEAK_TFLOPS)
+    return out, stack, peak
+
+
+def timed_run(coder, batches, steps, world, dist, cdev):
+    """K steps, software-pipelined, bracketed by barrier + synchronise; max over ranks.  -> (seconds, gathered stats)"""
+    from cnn_autoencoder_amd import slide
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    seq = [batches[k % len(batches)] for k in range(steps)]
+    fence()
+    t0 = time.perf_counter()
+    local_stats, _ = coder.run(seq)
+    local_stats = local_stats.to(cdev)
+    all_stats = slide.gather_stats(local_stats)  # the one collective of the path (RCCL all_gather)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, all_stats
+
+
+def profiled_run(coder, batches, steps, warmup, world, dist, cdev):
+    for k in range(warmup):
+        coder.run([batches[k % len(batches)]])
+    coder.enc.set_profiling(True)
+    coder.dec.set_profiling(True)
+    coder.enc.get_profile(reset=True)
+    coder.dec.get_profile(reset=True)
+    dt, stats = timed_run(coder, batches, steps, world, dist, cdev)
+    enc_ms, enc_calls = coder.enc.get_profile()
+    dec_ms, dec_calls = coder.dec.get_profile()
+    coder.enc.set_profiling(False)
+    coder.dec.set_profiling(False)
+    return dt, stats, (enc_ms, enc_calls, dec_ms, dec_calls)
+
+
+def make_coder(cae, slide, state, precision):
+    codec = cae.ConvolutionalAutoencoder(checkpoint=state)
+    for k in ('encoder', 'decoder'):
+        codec._model[k].module.precision = precision
+    return slide.SlideCoder(codec)
+
+
+def sub_run(cae, slide, cfg, state, precision, H, tiles_dev, steps, warmup, dist):
+    """A short N=1 run of another configuration, reported next to the headline: tiles/s, ms/step, dominant kernel."""
+    coder = make_coder(cae, slide, state, precision)
+    B = tiles_dev.shape[0]
+    batches = batch_variants(tiles_dev, 4)
+    dt, stats, prof = profiled_run(coder, batches, steps, warmup, 1, dist, tiles_dev.device)
+    kernels, stack, peak = kernel_table(cfg, H, B, *prof, precision)
+    dom = max(kernels, key=lambda k: k['ms'])
+    summ = slide.slide_summary(stats, H * H)
+    fallbacks = coder.enc.fp32_fallbacks + coder.dec.fp32_fallbacks
+    del coder
+    torch.cuda.empty_cache()
+    return dict(precision=precision, tile=H, tiles_per_step=B, steps=steps, tiles_per_s=steps * B / dt,
+                ms_per_step=1e3 * dt / steps, bpp=summ['bpp'], psnr_db=summ['psnr'],
+                dominant_kernel=dict(name=dom['name'], ms=dom['ms'], issued_tflops=dom['issued_tflops'],
+                                     peak=peak, frac=dom['frac_of_issued_peak'],
+                                     algorithmic_tflops=dom['algorithmic_tflops']),
+                analysis_conv_stack=stack, kernel_ms={k['name']: k['ms'] for k in kernels},
+                fp32_fallbacks=fallbacks)
 
 
 def main():
@@ -118,8 +237,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--tile', type=int, default=1024)
     ap.add_argument('--batch', type=int, default=32, help='tiles per step per GPU')
-    ap.add_argument('--distinct', type=int, default=4, help='distinct synthetic tiles per rank (tiled to the batch)')
+    ap.add_argument('--distinct', type=int, default=0,
+                    help='distinct synthetic tiles per rank (0 = one per batch slot); 4 flip/transpose variants of the '
+                         'batch are cycled over the steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sub-runs', action='store_true', help='skip the fp32_path / tile256 side runs')
     ap.add_argument('--precision', choices=['f16x3', 'fp32'], default='f16x3',
                     help='conv/GDN arithmetic: f16x3 = operands split into two f16 halves, 3 f16 MFMAs per product, '
                          'fp32 accumulate (fp32-class accuracy); fp32 = exact v_mfma_f32_32x32x2_f32')
@@ -147,86 +269,56 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    cdev = torch.device('cpu') if args.rehearse_on_one_gpu else dev  # gloo rehearsal: host tensors
 
-    os.environ['CAE_PRECISION'] = args.precision
     cfg = dict(synth.CANONICAL)
     state = synth.synthetic_state(cfg, seed=0)
-    codec = cae.ConvolutionalAutoencoder(checkpoint=state)
-    eb = codec._model['fact_ent'].module
+    coder = make_coder(cae, slide, state, args.precision)
+    eb = coder.eb
     eb.fit_quantiles()  # quantiles at the aux-loss fixed point, as after training
     eb.update(force=True)
     state['fact_ent'] = {k: v.detach().cpu() for k, v in eb.state_dict().items()}
-    coder = slide.SlideCoder(codec)
 
     H = args.tile
     B = args.batch
-    n_distinct = min(args.distinct, B)
-    first = rank * args.steps * B  # this rank's block of the slide, in chunk raster order
+    n_distinct = B if args.distinct <= 0 else min(args.distinct, B)
+    first = rank * B  # this rank's own tiles
     base = synth.histo_tiles(n_distinct, H, first_index=first)
     reps = (B + n_distinct - 1) // n_distinct
     tiles_host = np.concatenate([base] * reps)[:B]
     tiles_dev = torch.from_numpy(tiles_host).to(dev)
+    batches = batch_variants(tiles_dev, 4)
 
-    for _ in range(args.warmup):
-        coder.run([tiles_dev])
-    coder.enc.set_profiling(True)
-    coder.dec.set_profiling(True)
-    coder.enc.get_profile(reset=True)
-    coder.dec.get_profile(reset=True)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    # K steps, software-pipelined: the host range-codes batch k while the GPU runs batch k+1 / k-1
-    local_stats, _ = coder.run([tiles_dev] * args.steps)
-    cdev = torch.device('cpu') if args.rehearse_on_one_gpu else dev  # gloo rehearsal: host tensors
-    local_stats = local_stats.to(cdev)
-    all_stats = slide.gather_stats(local_stats)  # the one collective of the path (RCCL all_gather)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    enc_ms, enc_calls = coder.enc.get_profile()
-    dec_ms, dec_calls = coder.dec.get_profile()
-    coder.enc.set_profiling(False)
-    coder.dec.set_profiling(False)
+    dt, all_stats, prof = profiled_run(coder, batches, args.steps, args.warmup, world, dist, cdev)
 
     if rank == 0:
         total_tiles = world * args.steps * B
         summ = slide.slide_summary(all_stats, H * H)
-        enc_fl, dec_fl = layer_flops(cfg, H, H)
-        kernels = []
-        for i, f in enumerate(enc_fl):
-            kernels.append((f'analysis.{i} conv{"+GDN" if i < len(enc_fl) - 1 else ""}', f * B, enc_ms[1 + i] / max(enc_calls, 1)))
-        for i, f in enumerate(dec_fl):
-            kernels.append((f'synthesis.{i} deconv{"+IGDN" if i < len(dec_fl) - 1 else ""}', f * B, dec_ms[1 + i] / max(dec_calls, 1)))
-        dom = max(kernels, key=lambda k: k[2])
-        achieved = dom[1] / (dom[2] * 1e-3) / 1e12
-        # HBM bytes per launch of the dominant kernel: measured offline by rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE passes of this same command (profiles/r01_hbm_traffic.json, FETCH_SIZE doubled per
-        # the gfx950 correction); only valid for the profiled shape (batch 32, 1024x1024 tiles)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))[args.precision]
-            keys = {'fp32': {'analysis.1': 'conv_s2_kernel<3, 4, 4, true, 2, false>@4194304',
-                             'synthesis.2': 'deconv_s2_kernel<3, 4, 4, true>@4194304'},
-                    'f16x3': {'analysis.1': 'conv_s2_f16_kernel<3, 4, true>@2097152',
-                              'synthesis.2': 'deconv_s2_f16_kernel<3, 4, 8, 1, true>@4194304'}}[args.precision]
-            key = keys.get(dom[0].split(' ')[0])
-            if key and B == 32 and H == 1024:
-                traffic = tj[key]['hbm_mb'] * 1e6
-        except Exception:
-            traffic = None
-        gpu_ms = (sum(enc_ms) / max(enc_calls, 1), sum(dec_ms) / max(dec_calls, 1))
+        kernels, stack, peak = kernel_table(cfg, H, B, *prof, args.precision)
+        dom = max(kernels, key=lambda k: k['ms'])
+        # HBM bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+        # command, committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction); an OFFLINE value tied
+        # to the commit named in that file, only valid for the profiled shape (batch 32, 1024x1024 tiles)
+        traffic, traffic_source = None, None
+        keys = {'fp32': {'analysis.1': 'conv_s2_kernel<3, 4, 4, true, 2, false>@4194304',
+                         'synthesis.2': 'deconv_s2_kernel<3, 4, 4, true>@4194304'},
+                'f16x3': {'analysis.1': 'conv_s2_f16_kernel<3, 4, true>@2097152',
+                          'synthesis.2': 'deconv_s2_f16_kernel<3, 4, 8, 1, true>@4194304'}}[args.precision]
+        key = keys.get(dom['name'].split(' ')[0])
+        for name in ('r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
+            try:
+                tj = json.load(open(os.path.join(ROOT, 'profiles', name)))
+                if key and B == 32 and H == 1024 and key in tj[args.precision]:
+                    traffic = tj[args.precision][key]['hbm_mb'] * 1e6
+                    traffic_source = (f'profiles/{name}: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
+                                      f'command (build: {tj.get("commit", "see the note in that file")}); {key}')
+                    break
+            except Exception:
+                continue
+        gpu_ms = (sum(prof[0]) / max(prof[1], 1), sum(prof[2]) / max(prof[3], 1))
         f16 = args.precision == 'f16x3'
+        from cnn_autoencoder_amd import _lib
+        threads = int(_lib.lib().cae_coder_threads(coder.coder_threads, B))
         line = {
             'metric': 'tiles/sec, compress+decompress round trip of 1024x1024x3 histology tiles',
             'value': total_tiles / dt,
@@ -238,32 +330,63 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32 (f16x3 split MFMA: 3 f16 MFMAs per product, fp32 accumulate)' if args.precision == 'f16x3' else 'f32',
-            'data': f'synthetic: seeded procedural H&E-like tiles ({n_distinct} distinct per rank tiled to the batch), '
-                    'random-init canonical weights (seed 0), quantiles at the aux-loss fixed point',
+            'dtype': 'f32 (f16x3 split MFMA: 3 f16 MFMAs per product, fp32 accumulate)' if f16 else 'f32',
+            'data': f'synthetic: seeded procedural H&E-like tiles ({n_distinct} distinct per rank; 4 flip/transpose '
+                    'variants of the batch cycled over the steps), random-init canonical weights (seed 0), quantiles at '
+                    'the aux-loss fixed point',
             'config': {'workload': f'{H}x{H}x3 histology tiles, canonical 128/192/L4/k3 GDN model, '
                                    f'{B} tiles per step per GPU, encode+decode', 'tiles_per_step_per_gpu': B,
                        'tile': H, 'sharding': f'contiguous tile blocks over {world} rank(s), 1 all_gather of stats'},
-            'parity': {'bpp': summ['bpp'], 'psnr_db': summ['psnr'], 'tiles': summ['tiles']},
-            'roofline': {'bound': 'mfma', 'kernel': dom[0], 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                         'ms_per_launch': dom[2], 'flop_per_launch': dom[1],
-                         'note': ('algorithmic fp32 FLOP/s against the dense fp32 MFMA peak (SURVEY 8d denominator for '
-                                  'split-operand paths); the f16x3 kernels issue 3 f16 MFMA FLOP per algorithmic FLOP: '
-                                  'f16 MFMA rate = %.0f TFLOP/s = %.3f of the 2500 TFLOP/s dense f16 peak'
-                                  % (3 * achieved, 3 * achieved / 2500.0)) if f16 else
-                                 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32) against its dense peak'},
-            'kernels': [{'name': k[0], 'ms': k[2], 'tflops': k[1] / (k[2] * 1e-3) / 1e12 if k[2] > 0 else None}
-                        for k in kernels],
+            'slide_stats': {'bpp': summ['bpp'], 'psnr_db': summ['psnr'], 'tiles': summ['tiles']},
+            'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'achieved': dom['issued_tflops'], 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': dom['frac_of_issued_peak'], 'traffic': traffic,
+                         'traffic_source': traffic_source, 'ms_per_launch': dom['ms'],
+                         'flop_per_launch': dom['flop_per_launch'],
+                         'algorithmic_tflops': dom['algorithmic_tflops'],
+                         'algorithmic_vs_fp32_mfma_peak': dom['algorithmic_tflops'] / FP32_MFMA_PEAK_TFLOPS,
+                         'note': ('achieved = MFMA FLOP/s issued = 3 x algorithmic (three v_mfma_f32_32x32x16_f16 per '
+                                  'product) against the dense f16 MFMA peak' if f16 else
+                                  'exact fp32 MFMA (v_mfma_f32_32x32x2_f32) against its dense peak')},
+            'analysis_conv_stack': stack,
+            'kernels': kernels,
             'gpu_ms_per_step': {'analysis': gpu_ms[0], 'synthesis': gpu_ms[1]},
             'host_ms_per_step': {k: 1e3 * v / args.steps for k, v in coder.timers.items()},
-            'analysis_conv_stack_frac_of_fp32_mfma_peak':
-                (sum(enc_fl) * B / (sum(enc_ms[1:]) / max(enc_calls, 1) * 1e-3) / 1e12) / FP32_MFMA_PEAK_TFLOPS,
+            'host_coder_threads': threads,
+            'fp32_fallbacks': coder.enc.fp32_fallbacks + coder.dec.fp32_fallbacks,
         }
+        if threads:
+            line['host_cpu_ms_per_step'] = {k: 1e3 * v / args.steps * threads for k, v in coder.timers.items()
+                                            if k in ('host_encode', 'host_decode')}
+        line['cpu_baseline'] = None
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(state, cfg, list(tiles_host[:16]))
-        else:
-            line['cpu_baseline'] = None
+            report, per_tile, cpu_payloads, cpu_recs = cpu_baseline(state, cfg, list(tiles_host[:16]))
+            line['cpu_baseline'] = report
+            # the GPU path on exactly the tiles the oracle coded (BASELINE's "PSNR/bpp parity" at full tile size)
+            n = len(per_tile)
+            payloads, rec, stats = coder.roundtrip(tiles_dev[:n].contiguous())
+            rec = rec.cpu().numpy()
+            px = H * H
+            mse = lambda sse: sse / (px * 3)
+            psnr = lambda sse: 10 * np.log10(255.0 ** 2 / mse(sse)) if sse > 0 else float('inf')
+            diff = np.abs(rec.astype(np.int16) - np.stack(cpu_recs).astype(np.int16))
+            line['parity_vs_cpu'] = {
+                'tiles': n,
+                'bpp_gpu': 8.0 * float(stats[:, 0].sum()) / (n * px),
+                'bpp_cpu': 8.0 * sum(p[0] for p in per_tile) / (n * px),
+                'psnr_gpu': psnr(float(stats[:, 1].sum()) / n), 'psnr_cpu': psnr(sum(p[1] for p in per_tile) / n),
+                'bitstreams_identical': int(sum(a == b for a, b in zip(payloads, cpu_payloads))),
+                'max_abs_delta': int(diff.max()), 'pixels_differing_frac': float((diff > 0).mean()),
+                'note': 'max_abs_delta in uint8 levels between the GPU and the CPU reconstruction of the same tiles; a '
+                        'bitstream differs where a latent sits within float noise of a rounding boundary',
+            }
+        if world == 1 and not args.no_sub_runs:
+            other = 'fp32' if f16 else 'f16x3'
+            del coder
+            torch.cuda.empty_cache()
+            line[f'{other}_path'] = sub_run(cae, slide, cfg, state, other, H, tiles_dev, 16, 2, dist)
+            t256 = torch.from_numpy(synth.histo_tiles(64, 256, first_index=10_000)).to(dev)
+            t256 = torch.cat(batch_variants(t256, 8))  # 512 tiles per step
+            line['tile256'] = sub_run(cae, slide, cfg, state, args.precision, 256, t256, 16, 2, dist)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

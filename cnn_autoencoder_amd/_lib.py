@@ -63,6 +63,7 @@ SYMBOLS = {
     'cae_tile_sse': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
     'cae_model_set_profiling': (c_int, [c_void_p, c_int]),
     'cae_model_get_profile': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]),
+    'cae_coder_threads': (c_int, [c_int, c_int]),
     'cae_pmf_to_quantized_cdf': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'cae_rans_encode_batch': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),
     'cae_rans_decode_batch': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int]),

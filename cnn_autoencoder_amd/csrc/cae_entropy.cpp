@@ -427,6 +427,12 @@ int cae_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *c
     return CAE_OK;
 }
 
+int cae_coder_threads(int requested, int n_streams) {
+    int t = requested > 0 ? requested : default_threads();
+    if (n_streams > 0) t = std::min(t, n_streams);
+    return std::max(1, t);
+}
+
 int cae_rans_encode_batch(cae_model_t *mm, const int32_t *symbols, int n_streams, int hw, uint8_t **out_bufs,
                           size_t *out_lens, int threads) {
     Model *m = reinterpret_cast<Model *>(mm);

@@ -241,6 +241,9 @@ int cae_model_get_profile(cae_model_t *m, int track, double *ms, int n_slots, in
  * Streams are coded independently (one per tile), in parallel on `threads` host threads
  * (0 = $CAE_CODER_THREADS, else min(CPUs of this process, 16)).  Symbol order inside a stream is (c, y, x) raster; the CDF row
  * of a symbol is its channel c. */
+/* Size of the coder pool a cae_rans_*_batch call with `threads` = requested and n_streams streams uses. */
+int cae_coder_threads(int requested, int n_streams);
+
 int cae_pmf_to_quantized_cdf(const float *pmf_host, int n, int precision, uint32_t *cdf_host /* n+1 */);
 
 /* symbols_host: (n_streams, channels, hw) int32.  On success out_bufs[i] (library-allocated,
