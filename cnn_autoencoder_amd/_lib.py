@@ -54,6 +54,7 @@ SYMBOLS = {
     'cae_copy_to_host': (c_int, [c_void_p, c_void_p, c_size_t]),
     'cae_dequantize': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'cae_model_set_density': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float]),
+    'cae_model_set_likelihood_form': (c_int, [c_void_p, c_int]),
     'cae_likelihood': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cae_tile_ssim': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'cae_tile_delta_e': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -91,6 +91,22 @@ def load_state_dict(model, encoder=None, decoder=None, fact_ent=None, **kwargs):
         model['fact_ent'].update(force=True)
 
 
+def _load_checkpoint(path: str):
+    """torch.load restricted to tensors and plain containers.  The path of a 'cae' codec comes out of a .zarray file
+    (Codec.from_config), i.e. from whoever wrote the store: a pickle that needs more than the reference's schema
+    (numbers, strings, lists, dicts, tensors) is refused unless CAE_TRUSTED_CHECKPOINT=1 says the file is
+    trusted."""
+    import os
+    import pickle
+    try:
+        return torch.load(path, map_location='cpu', weights_only=True)
+    except pickle.UnpicklingError as e:
+        if os.environ.get('CAE_TRUSTED_CHECKPOINT') == '1':
+            return torch.load(path, map_location='cpu', weights_only=False)
+        raise ValueError(f'checkpoint {path!r} holds objects beyond tensors and plain containers ({e}); set '
+                         'CAE_TRUSTED_CHECKPOINT=1 to unpickle a file you trust') from e
+
+
 def autoencoder_from_state_dict(checkpoint, gpu=False, train=False) -> Dict[str, nn.Module]:
     """checkpoint: path to a ``torch.save``d dict or the dict itself (SURVEY §3.5 schema).
 
@@ -98,7 +114,7 @@ def autoencoder_from_state_dict(checkpoint, gpu=False, train=False) -> Dict[str,
     HIP device (there is no CPU path), one process per GPU.
     """
     if isinstance(checkpoint, str):
-        state = torch.load(checkpoint, map_location='cpu', weights_only=False)
+        state = _load_checkpoint(checkpoint)
     else:
         state = checkpoint
     model = setup_modules(**state)
@@ -204,7 +220,15 @@ class ConvolutionalAutoencoderBottleneck(_CodecBase):
 
     @staticmethod
     def _bytes2tensor(buf):
-        return torch.load(io.BytesIO(base64.b64decode(buf)), weights_only=False)
+        # the blob arrives through zarr metadata (Codec.from_config): tensors only, never a general unpickle
+        import pickle
+        try:
+            t = torch.load(io.BytesIO(base64.b64decode(buf)), weights_only=True)
+        except pickle.UnpicklingError as e:
+            raise ValueError(f'fact_ent_checkpoint entry is not a plain tensor: {e}') from e
+        if not isinstance(t, torch.Tensor):
+            raise ValueError(f'fact_ent_checkpoint entry is a {type(t).__name__}, expected a tensor')
+        return t
 
     @torch.no_grad()
     def encode(self, buf):

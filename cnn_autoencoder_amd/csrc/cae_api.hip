@@ -365,7 +365,7 @@ template <int R>
 static void launch_likelihood(Model *m, const float *y, int n, int hw, float *yhat, float *lik, double *part,
                               hipStream_t st) {
     hipLaunchKernelGGL(likelihood_kernel<R>, dim3(m->c_bn, n), dim3(256), 0, st, y, m->medians_dev, m->density_dev,
-                       m->density_per_channel, m->density_k, m->density_bound, m->c_bn, hw, yhat, lik, part);
+                       m->density_per_channel, m->density_k, m->density_bound, m->likelihood_plain, m->c_bn, hw, yhat, lik, part);
 }
 
 // (re)builds stage `stage` of a unit: a stride-1 (transposed) convolution cin -> cin with its epilogue
@@ -1252,6 +1252,15 @@ int cae_model_set_density(cae_model_t *mm, int channels, int n_filters, const in
     m->density_per_channel = per;
     m->density_bound = likelihood_bound > 0.f ? likelihood_bound : 0.f;
     m->density_dirty = true;
+    return CAE_OK;
+}
+
+int cae_model_set_likelihood_form(cae_model_t *mm, int form) {
+    Model *m = reinterpret_cast<Model *>(mm);
+    if (!m) return fail(CAE_ERR_ARG, "NULL model");
+    if (form != 0 && form != 1) return fail(CAE_ERR_ARG, "likelihood form must be 0 (plain) or 1 (sign trick)");
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->likelihood_plain = form == 0;
     return CAE_OK;
 }
 

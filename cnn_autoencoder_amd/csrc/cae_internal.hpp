@@ -71,6 +71,7 @@ struct Model {
     std::vector<float> density;
     int density_r = 0, density_k = 0, density_per_channel = 0;
     float density_bound = 0.f;
+    int likelihood_plain = 1;  // cae_model_set_likelihood_form
     float *density_dev = nullptr;
     bool density_dirty = false;
     double *bits_ws = nullptr;

@@ -962,7 +962,7 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x
 template <int R>
 __global__ void __launch_bounds__(256)
 likelihood_kernel(const float *__restrict__ y, const float *__restrict__ medians, const float *__restrict__ params,
-                  int per_channel, int K, float bound, int C, int HW, float *__restrict__ yhat,
+                  int per_channel, int K, float bound, int plain, int C, int HW, float *__restrict__ yhat,
                   float *__restrict__ lik, double *__restrict__ bits_part) {
     const int c = blockIdx.x, n = blockIdx.y;
     const float *pc = params + (size_t)c * per_channel;
@@ -975,7 +975,8 @@ likelihood_kernel(const float *__restrict__ y, const float *__restrict__ medians
         const float up = logits_cumulative<R>(pc, K, q + 0.5f);
         const float t = lo + up;
         const float sgn = t > 0.f ? -1.f : (t < 0.f ? 1.f : 0.f);
-        float pr = fabsf(sigmoidf(sgn * up) - sigmoidf(sgn * lo));
+        // plain: sigmoid(u) - sigmoid(l) (compressai >= 1.2.x); else the sign trick |sigmoid(s u) - sigmoid(s l)|
+        float pr = plain ? sigmoidf(up) - sigmoidf(lo) : fabsf(sigmoidf(sgn * up) - sigmoidf(sgn * lo));
         pr = fmaxf(pr, bound);
         if (yhat) yhat[base + i] = q;
         if (lik) lik[base + i] = pr;

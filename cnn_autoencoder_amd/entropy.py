@@ -63,19 +63,36 @@ def _logits_cumulative(params, n_filters: int, inputs: torch.Tensor) -> torch.Te
     return logits
 
 
-def _likelihood(params, n_filters: int, inputs: torch.Tensor):
+# Floating-point form of p = c(y + 1/2) - c(y - 1/2).  'plain' (default): sigmoid(u) - sigmoid(l), what compressai
+# >= 1.2.x is believed to compute (its `_likelihood` returns (likelihood, lower, upper) as this code assumes; the
+# reference requires compressai >= 1.2.4, requirements.txt:25).  'sign_trick': |sigmoid(s u) - sigmoid(s l)| with
+# s = -sign(l + u), the older compressai / tensorflow-compression form.  Equal in exact arithmetic; in fp32 the CDF
+# tables (hence bitstreams) can differ by one unit in the upper tail (tests/test_host.py shows where).  compressai
+# is absent from the build image, so the choice cannot be pinned: it is a named, switchable option
+# (EntropyBottleneck(likelihood_form=...) or CAE_LIKELIHOOD_FORM).
+LIKELIHOOD_FORMS = ('plain', 'sign_trick')
+
+
+def _likelihood(params, n_filters: int, inputs: torch.Tensor, form: str = 'plain'):
     lower = _logits_cumulative(params, n_filters, inputs - 0.5)
     upper = _logits_cumulative(params, n_filters, inputs + 0.5)
-    sign = -torch.sign(lower + upper).detach()
-    likelihood = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+    if form == 'plain':
+        likelihood = torch.sigmoid(upper) - torch.sigmoid(lower)
+    else:
+        sign = -torch.sign(lower + upper).detach()
+        likelihood = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
     return likelihood, lower, upper
 
 
 class EntropyBottleneck(nn.Module):
     def __init__(self, channels: int, *args, tail_mass: float = 1e-9, init_scale: float = 10,
                  filters: Sequence[int] = (3, 3, 3, 3), likelihood_bound: float = 1e-9,
-                 entropy_coder_precision: int = 16, **kwargs):
+                 entropy_coder_precision: int = 16, likelihood_form: Optional[str] = None, **kwargs):
         super().__init__()
+        import os
+        self.likelihood_form = likelihood_form or os.environ.get('CAE_LIKELIHOOD_FORM', 'plain')
+        if self.likelihood_form not in LIKELIHOOD_FORMS:
+            raise ValueError(f'likelihood_form must be one of {LIKELIHOOD_FORMS}, got {self.likelihood_form!r}')
         self.channels = int(channels)
         self.filters = tuple(int(f) for f in filters)
         self.init_scale = float(init_scale)
@@ -137,7 +154,7 @@ class EntropyBottleneck(nn.Module):
         return out
 
     def _likelihood(self, inputs: torch.Tensor, stop_gradient: bool = False):
-        return _likelihood(self._params(stop_gradient), len(self.filters), inputs)
+        return _likelihood(self._params(stop_gradient), len(self.filters), inputs, self.likelihood_form)
 
     def forward(self, x: torch.Tensor, training: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         if training is None:
@@ -168,7 +185,7 @@ class EntropyBottleneck(nn.Module):
             self.update()
         h = self._sync_handle()
         names = [n for n, _ in self.named_parameters(recurse=False) if n != 'quantiles']
-        ver = tuple((n, getattr(self, n)._version, getattr(self, n).data_ptr()) for n in names)
+        ver = tuple((n, getattr(self, n)._version, getattr(self, n).data_ptr()) for n in names) + (self.likelihood_form,)
         if self._density_version != ver:
             k = len(self.filters)
             params = self._params(cpu=True)
@@ -181,6 +198,7 @@ class EntropyBottleneck(nn.Module):
             pf = (ctypes.c_void_p * (k + 1))(*([a.ctypes.data for a in fact] + [None]))
             bound = float(self.likelihood_lower_bound.bound.item()) if self.use_likelihood_bound else 0.0
             _lib.check(_lib.lib().cae_model_set_density(h.ptr, self.channels, k, filt, pm, pb, pf, bound))
+            _lib.check(_lib.lib().cae_model_set_likelihood_form(h.ptr, LIKELIHOOD_FORMS.index(self.likelihood_form)))
             self._density_version = ver
         return h
 
@@ -254,7 +272,7 @@ class EntropyBottleneck(nn.Module):
         max_length = int(pmf_length.max().item())
         samples = torch.arange(max_length)
         samples = samples[None, :] + pmf_start[:, None, None]
-        pmf, lower, upper = _likelihood(params, len(self.filters), samples)
+        pmf, lower, upper = _likelihood(params, len(self.filters), samples, self.likelihood_form)
         pmf = pmf[:, 0, :]
         tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
         cdf = torch.zeros((len(pmf_length), max_length + 2), dtype=torch.int32)

@@ -116,11 +116,19 @@ class ZarrArray:
         meta = dict(zarr_format=ZARR_FORMAT, shape=[int(s) for s in shape], chunks=[int(c) for c in chunks],
                     dtype=np.dtype(dtype).str, compressor=compressor, fill_value=fill_value, order='C',
                     filters=None, dimension_separator='.')
+        try:
+            text = json.dumps(meta, indent=4, sort_keys=True)
+        except TypeError as e:  # e.g. a 'cae' codec built from an in-memory checkpoint dict
+            raise ValueError(f'the codec configuration cannot be stored in .zarray metadata ({e}): build the codec '
+                             'from a checkpoint PATH when writing a store') from e
+        # every rank creates the directories it writes chunk files into (a rank may finish its first batch before the
+        # metadata writer has run); only the metadata writer touches the .zgroup / .zarray files
+        if root is not None:
+            os.makedirs(root, exist_ok=True)
         if write_meta:
             _ensure_groups(store, component)
-            os.makedirs(root, exist_ok=True)
             with open(os.path.join(root, '.zarray'), 'w') as f:
-                json.dump(meta, f, indent=4, sort_keys=True)
+                f.write(text)
         return cls(root, meta, codec=codec if codec is not None else _Raw())
 
     @classmethod
@@ -214,6 +222,16 @@ def _rank_world():
     return 0, 1
 
 
+def _barrier():
+    """All ranks have written their chunk files (the store is complete when compress_image returns)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
+    except ImportError:
+        pass
+
+
 def _batches(items: Sequence, n: int) -> Iterable[Sequence]:
     for i in range(0, len(items), n):
         yield items[i:i + n]
@@ -235,6 +253,10 @@ def compress_image(codec: str, checkpoint, image: np.ndarray, output_filename: s
         data_group = '0/0'
     h, w, c = image.shape
     rank, world = _rank_world()
+    if 'CAE' in codec and not save_as_bottleneck and not isinstance(checkpoint, str):
+        # the 'cae' codec persists its checkpoint PATH in the .zarray metadata (_autoencoders.py:532): fail before
+        # the model is built, not when the metadata is written
+        raise ValueError("codec 'CAE' stores the checkpoint path in the array metadata: pass a path, not a dict")
 
     if 'CAE' in codec and save_as_bottleneck:
         import torch
@@ -259,6 +281,7 @@ def compress_image(codec: str, checkpoint, image: np.ndarray, output_filename: s
             for idx, s in zip(group, strings):
                 import struct
                 z.write_chunk_bytes(idx, struct.pack('>QQ', y.shape[2], y.shape[3]) + s)
+        _barrier()
         return z
 
     if 'CAE' in codec:
@@ -283,9 +306,11 @@ def compress_image(codec: str, checkpoint, image: np.ndarray, output_filename: s
         for group, payloads in zip(groups, stream):
             for idx, payload in zip(group, payloads):
                 z.write_chunk_bytes(idx, head + payload)
+        _barrier()
         return z
     for idx in tiles[lo:hi]:
         z.write_chunk(idx, image[z.chunk_slices(idx)])
+    _barrier()
     return z
 
 

@@ -180,10 +180,17 @@ int cae_model_set_density(cae_model_t *m, int channels, int n_filters, const int
                           const float *const *matrices, const float *const *biases,
                           const float *const *factors, float likelihood_bound);
 
+/* Form of the likelihood p = c(y + 1/2) - c(y - 1/2) in floating point: 0 (default) = sigmoid(u) - sigmoid(l), as
+ * compressai >= 1.2.x (`_likelihood` returning (likelihood, lower, upper), the version range the reference requires,
+ * requirements.txt:25) is believed to compute it; 1 = the older sign trick |sigmoid(s u) - sigmoid(s l)|,
+ * s = -sign(l + u).  Equal in exact arithmetic; in fp32 they differ in the last unit in the upper tail. */
+int cae_model_set_likelihood_form(cae_model_t *m, int form);
+
 /* EntropyBottleneck.__call__ in eval mode (reference call site models/tasks/_taskutils.py:97 and
  * the rate term -sum(log2 p) of models/criteria/_ratedist.py:49-54): for latents (n, channels, hw)
  *   y_hat = round(y - median_c) + median_c,
- *   likelihood = max(|sigmoid(s*u) - sigmoid(s*l)|, bound), l,u = logits_cumulative(y_hat -/+ 0.5),
+ *   likelihood = max(sigmoid(u) - sigmoid(l), bound), l,u = logits_cumulative(y_hat -/+ 0.5)
+ *                (form: cae_model_set_likelihood_form),
  *   bits[i] = -sum log2(likelihood) over tile i (float64, deterministic order).
  * Any of y_hat_dev / likelihood_dev / bits_dev may be NULL.  Needs set_entropy (medians) and
  * set_density.  Calls on one handle must be stream-ordered. */

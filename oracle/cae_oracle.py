@@ -332,7 +332,13 @@ class EntropyBottleneckOracle:
 
     def __init__(self, channels: int, filters: Sequence[int] = (3, 3, 3, 3),
                  init_scale: float = 10.0, tail_mass: float = 1e-9,
-                 likelihood_bound: float = 1e-9, generator: Optional[torch.Generator] = None):
+                 likelihood_bound: float = 1e-9, generator: Optional[torch.Generator] = None,
+                 likelihood_form: Optional[str] = None):
+        # 'plain' = sigmoid(u) - sigmoid(l): compressai >= 1.2.x as recalled (the reference requires >= 1.2.4);
+        # 'sign_trick' = |sigmoid(s u) - sigmoid(s l)|, s = -sign(l + u): older compressai.  Unpinned either way.
+        import os
+        self.likelihood_form = likelihood_form or os.environ.get('CAE_LIKELIHOOD_FORM', 'plain')
+        assert self.likelihood_form in ('plain', 'sign_trick')
         self.channels = int(channels)
         self.filters = tuple(int(f) for f in filters)
         self.init_scale = float(init_scale)
@@ -380,8 +386,11 @@ class EntropyBottleneckOracle:
     def likelihood(self, v: torch.Tensor):
         lower = self.logits_cumulative(v - 0.5)
         upper = self.logits_cumulative(v + 0.5)
-        sign = -torch.sign(lower + upper)
-        lik = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+        if self.likelihood_form == 'plain':
+            lik = torch.sigmoid(upper) - torch.sigmoid(lower)
+        else:
+            sign = -torch.sign(lower + upper)
+            lik = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
         return lik, lower, upper
 
     def forward(self, x: torch.Tensor, training: bool = False, generator=None):

@@ -50,3 +50,84 @@ def test_two_ranks_gather_identical_slide_stats(tmp_path, n_tiles):
     from cnn_autoencoder_amd import slide
     s = slide.slide_summary(st, 64 * 64)
     assert s['tiles'] == n_tiles and s['bytes'] == float((1000 + 7 * idx).sum())
+
+
+def _zarr_worker(rank, world, port, store, codec, shape, patch):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from cnn_autoencoder_amd import zarrio
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    img = np.random.default_rng(3).integers(0, 256, shape, dtype=np.uint8)  # every rank holds the same slide
+    zarrio.compress_image(codec, None, img, store, patch_size=patch, data_group='0/0')
+    # compress_image returns behind a barrier: the store is complete on every rank
+    back = zarrio.decompress_image(store, data_group='0/0')
+    assert np.array_equal(back, img), f'rank {rank} reads back a different image'
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('codec,shape,patch', [('Zlib', (150, 200, 3), 64), ('None', (70, 64, 1), 32),
+                                               ('Zlib', (64, 64, 3), 64)])
+def test_two_ranks_write_the_store_of_one_rank(tmp_path, codec, shape, patch):
+    """zarrio.compress_image under torch.distributed (compress.py:101,121-128 sharded over ranks): the ranks write
+    disjoint chunk files, rank 0 the metadata; the store is byte-identical to the one a single rank writes, including
+    the ragged last tile block, zero-padded edge chunks and a slide with fewer tiles than ranks."""
+    from cnn_autoencoder_amd import slide, zarrio
+    img = np.random.default_rng(3).integers(0, 256, shape, dtype=np.uint8)
+    one = str(tmp_path / 'one.zarr')
+    zarrio.compress_image(codec, None, img, one, patch_size=patch, data_group='0/0')
+    two = str(tmp_path / 'two.zarr')
+    world = 2
+    mp.spawn(_zarr_worker, args=(world, _free_port(), two, codec, shape, patch), nprocs=world, join=True)
+
+    def tree(root):
+        out = {}
+        for d, _, files in os.walk(root):
+            for f in files:
+                p = os.path.join(d, f)
+                out[os.path.relpath(p, root)] = open(p, 'rb').read()
+        return out
+    a, b = tree(one), tree(two)
+    assert sorted(a) == sorted(b)
+    assert all(a[k] == b[k] for k in a)
+    n_tiles = -(-shape[0] // patch) * -(-shape[1] // patch)
+    assert len([k for k in a if not os.path.basename(k).startswith('.')]) == n_tiles
+    assert slide.tile_range(0, 2, n_tiles)[1] == slide.tile_range(1, 2, n_tiles)[0]
+
+
+def _cae_worker(rank, world, port, store, ckpt, shape, patch):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from cnn_autoencoder_amd import zarrio
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)  # one-GPU box: both ranks on cuda:0, collective on gloo
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    img = np.random.default_rng(7).integers(0, 256, shape, dtype=np.uint8)
+    zarrio.compress_image('CAE', ckpt, img, store, patch_size=patch, data_group='0/0', batch_tiles=2)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_write_the_cae_store_of_one_rank(tmp_path):
+    """The same with the 'cae' codec on the HIP path (two ranks sharing the one GPU of the test box): chunk
+    bitstreams, metadata and the decoded image equal the single-rank store; 7 tiles over 2 ranks (ragged), edge
+    chunks padded to the full patch."""
+    from cnn_autoencoder_amd import synth, zarrio
+    cfg = dict(synth.CANONICAL, channels_net=32, channels_bn=48, compression_level=3)
+    ckpt = str(tmp_path / 'ckpt.pth')
+    torch.save(synth.synthetic_state(cfg, seed=4), ckpt)
+    shape, patch = (200, 150, 3), 64
+    img = np.random.default_rng(7).integers(0, 256, shape, dtype=np.uint8)
+    one = str(tmp_path / 'one.zarr')
+    zarrio.compress_image('CAE', ckpt, img, one, patch_size=patch, data_group='0/0', batch_tiles=2)
+    two = str(tmp_path / 'two.zarr')
+    mp.spawn(_cae_worker, args=(2, _free_port(), two, ckpt, shape, patch), nprocs=2, join=True)
+    files = sorted(os.listdir(os.path.join(one, '0', '0')))
+    assert files == sorted(os.listdir(os.path.join(two, '0', '0'))) and len(files) == 12 + 1
+    for f in files:
+        assert open(os.path.join(one, '0', '0', f), 'rb').read() == open(os.path.join(two, '0', '0', f), 'rb').read(), f
+    assert np.array_equal(zarrio.decompress_image(one), zarrio.decompress_image(two))

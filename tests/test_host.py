@@ -440,3 +440,62 @@ def test_slide_summary_math():
     assert abs(s['bpp'] - 8 * 4000 / (2 * 64 * 64)) < 1e-12
     mse = 400.0 / (2 * 64 * 64 * 3)
     assert abs(s['psnr'] - 10 * np.log10(255 ** 2 / mse)) < 1e-9
+
+
+def test_untrusted_metadata_is_not_unpickled(cae, tmp_path):
+    """fact_ent_checkpoint blobs and checkpoint paths arrive through .zarray metadata (Codec.from_config): only
+    tensors / plain containers are loaded, anything else is refused (weights_only)."""
+    import base64
+    import io
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('true',))
+
+    blob = base64.b64encode(pickle.dumps(Evil())).decode('ascii')
+    with pytest.raises((ValueError, pickle.UnpicklingError)):
+        cae.ConvolutionalAutoencoderBottleneck(channels_bn=4, filters=[3, 3], fact_ent_checkpoint={'quantiles': blob})
+    buf = io.BytesIO()
+    torch.save({'not': 'a tensor'}, buf)
+    with pytest.raises(ValueError, match='expected a tensor'):
+        cae.ConvolutionalAutoencoderBottleneck._bytes2tensor(base64.b64encode(buf.getvalue()).decode('ascii'))
+    path = str(tmp_path / 'evil.pth')
+    with open(path, 'wb') as f:
+        pickle.dump({'channels_bn': 4, 'x': Evil()}, f)
+    with pytest.raises((ValueError, pickle.UnpicklingError)):
+        cae.codec._load_checkpoint(path)
+
+
+def test_likelihood_forms_agree_except_where_float_rounding_decides(cae):
+    """The two floating-point forms of the bin probability (entropy.LIKELIHOOD_FORMS: 'plain' = compressai >= 1.2.x as
+    recalled, 'sign_trick' = older) are equal in exact arithmetic.  On the canonical model they give the same CDF row
+    for almost every channel; where one pmf entry rounds to a different 16-bit frequency the stealing loop of
+    pmf_to_quantized_cdf reshuffles that row, so bitstreams of the two forms are NOT interchangeable: the form is a
+    named option, and product and oracle agree on each."""
+    from cnn_autoencoder_amd import synth
+    from oracle import cae_oracle as O
+    state = synth.synthetic_state(synth.CANONICAL, seed=0)
+    tables = {}
+    for form in cae.entropy.LIKELIHOOD_FORMS:
+        eb = cae.EntropyBottleneck(192, filters=[3] * 4, likelihood_form=form)
+        eb.load_state_dict(state['fact_ent'], strict=False)
+        eb.fit_quantiles()
+        eb.update(force=True)
+        o = O.EntropyBottleneckOracle(192, likelihood_form=form)
+        o.load(eb.state_dict())
+        o.update()
+        assert torch.equal(o._quantized_cdf, eb._quantized_cdf) and torch.equal(o._cdf_length, eb._cdf_length)
+        cdf = eb._quantized_cdf
+        for c in range(192):
+            row = cdf[c, :int(eb._cdf_length[c])]
+            assert row[0] == 0 and row[-1] == 65536 and bool((row[1:] > row[:-1]).all())
+        tables[form] = cdf
+        # same values where float noise cannot matter: in-support probabilities of the first channel
+        v = torch.linspace(-3, 3, 7).view(1, 1, -1).repeat(192, 1, 1)
+        tables[form + '_p'] = cae.entropy._likelihood(eb._params(cpu=True), 4, v, form)[0]
+    np.testing.assert_allclose(tables['plain_p'].numpy(), tables['sign_trick_p'].numpy(), rtol=2e-6, atol=3e-7)  # (plain: cancellation near sigmoid = 1)
+    differing_rows = int((tables['plain'] != tables['sign_trick']).any(dim=1).sum())
+    assert 0 < differing_rows <= 10, f'{differing_rows} of 192 CDF rows differ between the two forms'
+    with pytest.raises(ValueError):
+        cae.EntropyBottleneck(4, likelihood_form='other')

@@ -57,6 +57,18 @@ def test_output_to_tile_truncates():
 #        main: q=2^24 r=17 -> x=2^40+17+32768 -> lo 0x00008011 hi 0x00000100
 #  renormalise_once   : cdf [0,1,65536]; sym 0 (freq 1): x_max=2^47; 1st: x=2^31<<16=2^47;
 #        2nd: x>=x_max -> emit lo32(2^47)=0, x=2^15 -> x=2^31; flush lo=0x80000000 hi=0, then the emitted 0
+#  two_digit_bypass   : cdf [0,32768,65536], max_value 1; sym 9 >= 1 -> raw = 2(9-1) = 16 = 0x10: two digits, low first
+#        (0, 1).  Stack: main, count 2, digit 0, digit 1; popped in reverse: bypass(1): x=(2^31<<4)|1=2^35+1;
+#        bypass(0): x=2^39+16; bypass(2): x=2^43+258; main (start 2^15, freq 2^15): q=2^28, r=258 ->
+#        x=2^44+258+32768=2^44+0x8102 -> lo 0x00008102 hi 0x00001000
+#  seven_digits_with_renormalisation : sym -2^27 -> raw = 2^28-1 (odd: negative), seven digits 0xF.  Seven bypass(15):
+#        x = 2^59 + 2^28 - 1; bypass(count 7): x >= x_max = 2^59 -> emit lo32 = 0x0FFFFFFF, x = 2^27 ->
+#        x = (2^27<<4)|7 = 2^31+7; main: q = 2^16, r = 7 -> x = 2^32+7+32768 -> lo 0x00008007 hi 1, then the emitted word.
+#        (raw is 32-bit upstream and < 2^28 here: at most 8 (7) digits, so the `count >= 15` unary continuation of the
+#        digit count can never run; this is the longest count that can be coded.)
+#  cdf [1e-9,.75,.25] : rounds to [0,49152,16384], sums [0,0,49152,65536]; entry 0 has freq 0: the smallest freq > 1 is
+#        entry 2 (16384), i.e. best_steal > i -> cdf[1..2] += 1 -> [0,1,49153,65536]
+#  cdf [1e-9,.5,.5]   : freqs [0,32768,32768]: ties go to the FIRST smallest (strict <) = entry 1 -> cdf[1] += 1
 with open(os.path.join(GOLD, 'rans_kat.json')) as f:
     KAT = json.load(f)
 
