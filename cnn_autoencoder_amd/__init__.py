@@ -18,4 +18,4 @@ __all__ = ['Analyzer', 'Synthesizer', 'GDN', 'EntropyBottleneck', 'DownsamplingU
            'initialize_weights', 'setup_modules', 'load_state_dict', 'autoencoder_from_state_dict',
            'ConvolutionalAutoencoder', 'ConvolutionalAutoencoderBottleneck', 'register_codecs',
            'pmf_to_quantized_cdf', 'build', 'CaeError', 'LIB_PATH']
-from . import criteria, metrics  # noqa: F401,E402  (validation objective; GPU metrics of the reference harness)
+from . import criteria, metrics, train  # noqa: F401,E402  (validation objective; GPU metrics of the reference harness)

@@ -64,6 +64,25 @@ SYMBOLS = {
     'cae_tile_sse': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
     'cae_model_set_profiling': (c_int, [c_void_p, c_int]),
     'cae_model_get_profile': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]),
+    'cae_t_packed_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cae_t_pack_weights': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cae_t_from_nchw': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'cae_t_to_nchw': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cae_t_conv_forward': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_void_p]),
+    'cae_t_conv_dgrad_ext': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                                      c_void_p]),
+    'cae_t_deconv_forward': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_void_p]),
+    'cae_t_deconv_dgrad': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                    c_void_p]),
+    'cae_t_wgrad': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                             c_void_p]),
+    'cae_t_gdn_forward': (c_int, [c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'cae_t_gdn_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cae_t_fold_to_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cae_t_colsum': (c_int, [c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p]),
     'cae_coder_threads': (c_int, [c_int, c_int]),
     'cae_pmf_to_quantized_cdf': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'cae_rans_encode_batch': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),

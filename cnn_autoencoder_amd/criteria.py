@@ -3,9 +3,10 @@
 ``DistMSELoss`` (``_ratedist.py:45-63``) assembled as ``GeneralLoss`` does (``_lossutils.py:54-72,100-109``):
 ``loss = lambda * 255^2 * MSE(x_r, x) + (-sum log2 p_y / (B H W))`` plus the reported ``entropy_loss``.
 
-No-grad only: the analysis / synthesis tracks and the eval-mode density run on the HIP kernels, which have no backward
-(training is SURVEY §8f.3).  Classifier / segmentation heads, penalty terms and the MS-SSIM / pyramid distortions of
-the reference are outside the hot path and not built.
+Under ``torch.no_grad()`` the analysis / synthesis tracks and the eval-mode density run on the inference kernels; with
+autograd recording (``train.train_step``) the tracks switch to the training kernels with hand-written backward
+(``train.py``) and the entropy model adds its uniform noise (train mode).  Classifier / segmentation heads, penalty
+terms and the MS-SSIM / pyramid distortions of the reference are outside the hot path and not built.
 """
 from __future__ import annotations
 
@@ -24,8 +25,6 @@ def setup_forward_func(enabled_modules: Sequence[str] = ('encoder', 'fact_ent', 
         raise NotImplementedError(f'modules outside the compression path are not built: {sorted(unknown)}')
 
     def forward_func(x, model) -> Dict:
-        if torch.is_grad_enabled():
-            raise NotImplementedError('the HIP tracks have no backward: call under torch.no_grad()')
         y = model['encoder'](x) if 'encoder' in enabled else x
         y_q, p_y = model['fact_ent'](y) if 'fact_ent' in enabled else (y, None)
         x_r, fx_brg = model['decoder'](y_q) if 'decoder' in enabled else (y_q, None)

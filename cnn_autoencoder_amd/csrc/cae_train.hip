@@ -1,0 +1,417 @@
+// C ABI of the training path (include/cae_hip.h, "training"): stateless launches on caller-owned device buffers.
+#include "cae_hip.h"
+#include "cae_internal.hpp"
+#include "cae_launch.hpp"
+#include "cae_train_kernels.hpp"
+
+#include <algorithm>
+
+using namespace cae;
+using namespace cae::tr;
+
+namespace {
+
+const void *zero_page() {
+    static void *z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 1024) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 1024);
+    }
+    return z;
+}
+
+unsigned ew_grid(size_t total) {
+    const size_t b = (total + 255) / 256;
+    return (unsigned)std::min<size_t>(std::max<size_t>(b, 1), 256 * 8 * 4);
+}
+
+bool bad_channels(int c) { return c < 32 || c % 32 != 0 || c > 192; }
+
+template <int NT>
+int launch_gg_t(const GGArgs &a, size_t lds, hipStream_t st) {
+    auto kern = gather_gemm_kernel<NT>;
+    static size_t attr = 0;
+    if (lds > attr) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    const unsigned grid = (unsigned)((size_t)a.N * a.tiles_x * a.tiles_y);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+// fills the halo / staging geometry of `a` from its tap list and launches
+int launch_gg(GGArgs &a, hipStream_t st) {
+    if (bad_channels(a.Ck) || bad_channels(a.Cn)) return fail(CAE_ERR_ARG, "channel counts must be multiples of 32, at most 192");
+    if (a.ntaps < 1 || a.ntaps > MAX_TAPS) return fail(CAE_ERR_ARG, "bad tap count");
+    int dymin = a.dy[0], dymax = a.dy[0], dxmin = a.dx[0], dxmax = a.dx[0];
+    for (int t = 1; t < a.ntaps; ++t) {
+        dymin = std::min<int>(dymin, a.dy[t]);
+        dymax = std::max<int>(dymax, a.dy[t]);
+        dxmin = std::min<int>(dxmin, a.dx[t]);
+        dxmax = std::max<int>(dxmax, a.dx[t]);
+    }
+    a.dymin = dymin;
+    a.dxmin = dxmin;
+    a.HR = a.S * 15 + (dymax - dymin) + 1;
+    a.HC = a.S * 15 + (dxmax - dxmin) + 1;
+    const int NT = a.Cn / 32;
+    const int pieces = 4 * a.HR * a.HC;
+    if ((pieces + 63) / 64 > 80) return fail(CAE_ERR_UNSUPPORTED, "halo too large");
+    const size_t halo = (size_t)((pieces + 63) / 64) * 1024;
+    const size_t budget = 160 * 1024 - halo;
+    a.taps_per_stage = std::min<int>(a.ntaps, (int)(budget / ((size_t)NT * 2048)));
+    if (a.taps_per_stage < 1) return fail(CAE_ERR_UNSUPPORTED, "weights of one tap do not fit the LDS");
+    const size_t lds = halo + (size_t)a.taps_per_stage * NT * 2048;
+    a.tiles_x = (a.LW + 15) / 16;
+    a.tiles_y = (a.LH + 15) / 16;
+    a.zero = zero_page();
+    if (!a.zero) return fail(CAE_ERR_NOMEM, "zero page");
+    switch (NT) {
+        case 1: return launch_gg_t<1>(a, lds, st);
+        case 2: return launch_gg_t<2>(a, lds, st);
+        case 3: return launch_gg_t<3>(a, lds, st);
+        case 4: return launch_gg_t<4>(a, lds, st);
+        case 5: return launch_gg_t<5>(a, lds, st);
+        default: return launch_gg_t<6>(a, lds, st);
+    }
+}
+
+// strided correlation: position (i, j) <- input (2i + ky - P, 2j + kx - P), every tap
+int strided_corr(const void *in16, int n, int ih, int iw, int ck, const void *packed, int ks, int reflect, float *out32,
+                 void *out16, int cn, int oh, int ow, const float *bias, hipStream_t st) {
+    if (ks != 3 && ks != 5) return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+    GGArgs a{};
+    a.in = in16;
+    a.out32 = out32;
+    a.out16 = out16;
+    a.wp = packed;
+    a.bias = bias;
+    a.N = n;
+    a.IH = ih;
+    a.IW = iw;
+    a.Ck = ck;
+    a.Cn = cn;
+    a.OH = oh;
+    a.OW = ow;
+    a.LH = oh;
+    a.LW = ow;
+    a.S = 2;
+    a.SO = 1;
+    a.reflect = reflect;
+    a.ktaps = ks * ks;
+    a.ntaps = ks * ks;
+    const int P = ks / 2;
+    for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx) {
+            const int t = ky * ks + kx;
+            a.dy[t] = (short)(ky - P);
+            a.dx[t] = (short)(kx - P);
+            a.wt[t] = (short)t;
+        }
+    return launch_gg(a, st);
+}
+
+// transpose of the strided correlation, one launch per output parity.
+//   shift = P : cropped domain   out[Y] = sum in[(Y + P - ky) / 2]  (ConvTranspose2d(k, 2, k//2, output_padding 1))
+//   shift = 0 : extended domain  out[Y] = sum in[(Y - ky) / 2],  Y in [0, 2 ih + k - 2]   (data gradient of a valid
+//               convolution on the reflect-padded input; Y = y + P)
+int strided_corr_t(const void *in16, int n, int ih, int iw, int ck, const void *packed, int ks, int shift, float *out32,
+                   void *out16, int cn, int oh, int ow, const float *bias, hipStream_t st) {
+    if (ks != 3 && ks != 5) return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            GGArgs a{};
+            a.in = in16;
+            a.out32 = out32;
+            a.out16 = out16;
+            a.wp = packed;
+            a.bias = bias;
+            a.N = n;
+            a.IH = ih;
+            a.IW = iw;
+            a.Ck = ck;
+            a.Cn = cn;
+            a.OH = oh;
+            a.OW = ow;
+            a.LH = (oh - py + 1) / 2;
+            a.LW = (ow - px + 1) / 2;
+            if (a.LH < 1 || a.LW < 1) continue;
+            a.S = 1;
+            a.SO = 2;
+            a.oy0 = py;
+            a.ox0 = px;
+            a.reflect = 0;
+            a.ktaps = ks * ks;
+            int nt = 0;
+            for (int ky = 0; ky < ks; ++ky) {
+                if (((py + shift - ky) & 1) != 0) continue;
+                for (int kx = 0; kx < ks; ++kx) {
+                    if (((px + shift - kx) & 1) != 0) continue;
+                    a.dy[nt] = (short)((py + shift - ky) / 2);  // exact: the numerator is even
+                    a.dx[nt] = (short)((px + shift - kx) / 2);
+                    a.wt[nt] = (short)(ky * ks + kx);
+                    ++nt;
+                }
+            }
+            a.ntaps = nt;
+            if (nt == 0) continue;
+            int rc = launch_gg(a, st);
+            if (rc) return rc;
+        }
+    return CAE_OK;
+}
+
+template <int NB>
+int launch_wg_t(const WGArgs &a, size_t lds, int ksplit, int at, int tg, hipStream_t st) {
+    auto kern = wgrad_kernel<NB>;
+    static size_t attr = 0;
+    if (lds > attr) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(ksplit, at, tg), dim3(256), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+template <int CT, int MODE>
+int launch_gdn_a_t(const GdnArgs &a, hipStream_t st) {
+    auto kern = gdn_gemm_a_kernel<CT, MODE>;
+    constexpr int LDS = CT * 32 * (CT * 32 + 4) * 4;
+    static bool done = false;
+    if (!done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        done = true;
+    }
+    const long tiles = (a.pixels + 255) / 256;
+    const unsigned grid = (unsigned)std::min<long>(tiles, 512);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+template <int MODE>
+int launch_gdn_a(const GdnArgs &a, hipStream_t st) {
+    switch (a.C / 32) {
+        case 1: return launch_gdn_a_t<1, MODE>(a, st);
+        case 2: return launch_gdn_a_t<2, MODE>(a, st);
+        case 3: return launch_gdn_a_t<3, MODE>(a, st);
+        case 4: return launch_gdn_a_t<4, MODE>(a, st);
+        case 5: return launch_gdn_a_t<5, MODE>(a, st);
+        default: return launch_gdn_a_t<6, MODE>(a, st);
+    }
+}
+
+template <int CT>
+int launch_gdn_b_t(const float *gn, const float *z, long pixels, float *gg, float *gb, hipStream_t st) {
+    const unsigned grid = (unsigned)std::min<long>(std::max<long>(pixels / 256, 1), 256);
+    hipLaunchKernelGGL(gdn_gemm_b_kernel<CT>, dim3(grid), dim3(CT * 64), 0, st, gn, z, pixels, gg, gb);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cae_t_packed_bytes(int contract_channels, int out_channels, int kernel_size) {
+    const size_t q = (contract_channels + 31) / 32, nt = (out_channels + 31) / 32;
+    return q * kernel_size * kernel_size * nt * 2 * 512 * 2;
+}
+
+int cae_t_pack_weights(const float *w, int dim0, int dim1, int ks, int contract_dim, void *packed, void *stream) {
+    if (!w || !packed) return fail(CAE_ERR_ARG, "NULL argument");
+    if (dim0 < 1 || dim1 < 1 || (contract_dim != 0 && contract_dim != 1)) return fail(CAE_ERR_ARG, "bad weight shape");
+    const int kk = ks * ks;
+    const int Kc = contract_dim == 0 ? dim0 : dim1, Nc = contract_dim == 0 ? dim1 : dim0;
+    const long s0 = (long)dim1 * kk, s1 = kk;  // element strides of dim0 / dim1
+    const long sk = contract_dim == 0 ? s0 : s1, sn = contract_dim == 0 ? s1 : s0;
+    const int kchunks = (Kc + 31) / 32, NT = (Nc + 31) / 32;
+    const size_t total = (size_t)kchunks * kk * NT * 1024;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, (__bf16 *)packed, Kc,
+                       Nc, kk, sk, sn, kchunks, NT);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_t_from_nchw(const float *x, int n, int c, int h, int w, int cp, void *out16, float *out32, void *stream) {
+    if (!x || (!out16 && !out32)) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || c < 1 || h < 1 || w < 1 || cp < c || cp % 32) return fail(CAE_ERR_ARG, "bad shape");
+    hipLaunchKernelGGL(nchw_to_t_kernel, dim3(ew_grid((size_t)n * h * w * cp)), dim3(256), 0, (hipStream_t)stream, x,
+                       (__bf16 *)out16, out32, n, c, h, w, cp);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_t_to_nchw(const float *t32, int n, int c, int h, int w, int cp, float *out, void *stream) {
+    if (!t32 || !out) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || c < 1 || h < 1 || w < 1 || cp < c || cp % 32) return fail(CAE_ERR_ARG, "bad shape");
+    hipLaunchKernelGGL(t_to_nchw_kernel, dim3(ew_grid((size_t)n * c * h * w)), dim3(256), 0, (hipStream_t)stream, t32, out, n,
+                       c, h, w, cp);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_t_conv_forward(const void *x16, int n, int h, int w, int cin_p, const void *packed, int ks, float *z32, void *z16,
+                       int cout_p, const float *bias, void *stream) {
+    if (!x16 || !packed || (!z32 && !z16)) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 2 || w < 2) return fail(CAE_ERR_ARG, "bad shape");
+    return strided_corr(x16, n, h, w, cin_p, packed, ks, 1, z32, z16, cout_p, (h + 1) / 2, (w + 1) / 2, bias,
+                        (hipStream_t)stream);
+}
+
+int cae_t_conv_dgrad_ext(const void *gz16, int n, int oh, int ow, int cout_p, const void *packed, int ks, int h, int w,
+                         float *gext32, int cin_p, void *stream) {
+    if (!gz16 || !packed || !gext32) return fail(CAE_ERR_ARG, "NULL argument");
+    if (oh != (h + 1) / 2 || ow != (w + 1) / 2) return fail(CAE_ERR_ARG, "gradient shape does not match the input shape");
+    const int P = ks / 2, eh = h + 2 * P, ew = w + 2 * P;
+    // rows / columns of the extended domain beyond 2 oh + k - 2 (odd input sizes) receive no contribution
+    HIP_TRY(hipMemsetAsync(gext32, 0, (size_t)n * eh * ew * cin_p * sizeof(float), (hipStream_t)stream));
+    return strided_corr_t(gz16, n, oh, ow, cout_p, packed, ks, 0, gext32, nullptr, cin_p, eh, ew, nullptr, (hipStream_t)stream);
+}
+
+int cae_t_deconv_forward(const void *x16, int n, int h, int w, int cin_p, const void *packed, int ks, float *z32, void *z16,
+                         int cout_p, const float *bias, void *stream) {
+    if (!x16 || !packed || (!z32 && !z16)) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 1 || w < 1) return fail(CAE_ERR_ARG, "bad shape");
+    return strided_corr_t(x16, n, h, w, cin_p, packed, ks, ks / 2, z32, z16, cout_p, 2 * h, 2 * w, bias, (hipStream_t)stream);
+}
+
+int cae_t_deconv_dgrad(const void *gz16, int n, int h, int w, int cout_p, const void *packed, int ks, float *gx32, void *gx16,
+                       int cin_p, void *stream) {
+    if (!gz16 || !packed || (!gx32 && !gx16)) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 1 || w < 1) return fail(CAE_ERR_ARG, "bad shape");
+    return strided_corr(gz16, n, 2 * h, 2 * w, cout_p, packed, ks, 0, gx32, gx16, cin_p, h, w, nullptr, (hipStream_t)stream);
+}
+
+int cae_t_wgrad(const void *xbig16, int n, int h, int w, int ca, const void *ysmall16, int oh, int ow, int cb, int ks,
+                int reflect, float *gw32, void *stream) {
+    if (!xbig16 || !ysmall16 || !gw32) return fail(CAE_ERR_ARG, "NULL argument");
+    if (ks != 3 && ks != 5) return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+    if (bad_channels(ca) || bad_channels(cb)) return fail(CAE_ERR_ARG, "channel counts must be multiples of 32, at most 192");
+    if (n < 1 || oh < 1 || ow < 1 || 2 * oh < h || 2 * ow < w) return fail(CAE_ERR_ARG, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    WGArgs a{};
+    a.x = xbig16;
+    a.y = ysmall16;
+    a.gw = gw32;
+    a.zero = zero_page();
+    if (!a.zero) return fail(CAE_ERR_NOMEM, "zero page");
+    a.N = n;
+    a.H = h;
+    a.W = w;
+    a.Ca = ca;
+    a.OH = oh;
+    a.OW = ow;
+    a.Cb = cb;
+    a.reflect = reflect;
+    a.kk = ks * ks;
+    const int P = ks / 2;
+    for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx) {
+            a.dy[ky * ks + kx] = (short)(ky - P);
+            a.dx[ky * ks + kx] = (short)(kx - P);
+        }
+    a.dymin = -P;
+    a.dxmin = -P;
+    a.HR = 2 * 7 + ks;
+    a.HC = 2 * 15 + ks;
+    a.tiles_x = (ow + 15) / 16;
+    a.tiles_y = (oh + 7) / 8;
+    a.total_tiles = n * a.tiles_x * a.tiles_y;
+    HIP_TRY(hipMemsetAsync(gw32, 0, (size_t)a.kk * ca * cb * sizeof(float), st));
+    const size_t lds = (size_t)((a.HR * a.HC * 4 + 63) / 64) * 1024 + (size_t)((128 * (cb / 8) + 63) / 64) * 1024;
+    const int a_tiles = ca / 32, tap_groups = (a.kk + 8) / 9;
+    const int ksplit = std::max(1, std::min(a.total_tiles, 512 / (a_tiles * tap_groups)));
+    if (cb / 32 <= 4) return launch_wg_t<1>(a, lds, ksplit, a_tiles, tap_groups, st);
+    return launch_wg_t<2>(a, lds, ksplit, a_tiles, tap_groups, st);
+}
+
+int cae_t_gdn_forward(const float *z32, long pixels, int cp, const float *beta, const float *gamma, int inverse, float *y32,
+                      void *y16, void *stream) {
+    if (!z32 || !beta || !gamma || (!y32 && !y16)) return fail(CAE_ERR_ARG, "NULL argument");
+    if (pixels < 1 || bad_channels(cp)) return fail(CAE_ERR_ARG, "bad shape");
+    GdnArgs a{};
+    a.a = z32;
+    a.mat = gamma;
+    a.beta = beta;
+    a.z = z32;
+    a.o32a = y32;
+    a.o16 = y16;
+    a.pixels = pixels;
+    a.C = cp;
+    a.inverse = inverse;
+    return launch_gdn_a<0>(a, (hipStream_t)stream);
+}
+
+int cae_t_gdn_backward(const float *z32, const float *gext32, int n, int h, int w, int pad, int cp, const float *beta,
+                       const float *gamma, const float *gamma_t, int inverse, float *gn_ws32, float *gzd_ws32, float *gz32,
+                       void *gz16, float *ggamma, float *gbeta, void *stream) {
+    if (!z32 || !gext32 || !beta || !gamma || !gamma_t || !gn_ws32 || !gzd_ws32 || (!gz32 && !gz16) || !ggamma || !gbeta)
+        return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 1 || w < 1 || pad < 0 || bad_channels(cp)) return fail(CAE_ERR_ARG, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const long pixels = (long)n * h * w;
+    GdnArgs a{};
+    a.a = z32;
+    a.mat = gamma;
+    a.beta = beta;
+    a.z = z32;
+    a.gy = FoldSrc{gext32, h, w, pad};
+    a.img_h = h;
+    a.img_w = w;
+    a.o32a = gn_ws32;
+    a.o32b = gzd_ws32;
+    a.pixels = pixels;
+    a.C = cp;
+    a.inverse = inverse;
+    int rc = launch_gdn_a<1>(a, st);
+    if (rc) return rc;
+    GdnArgs b{};
+    b.a = gn_ws32;
+    b.mat = gamma_t;
+    b.z = z32;
+    b.o32a = gz32;
+    b.o32b = gzd_ws32;
+    b.o16 = gz16;
+    b.pixels = pixels;
+    b.C = cp;
+    b.inverse = inverse;
+    if ((rc = launch_gdn_a<2>(b, st))) return rc;
+    HIP_TRY(hipMemsetAsync(ggamma, 0, (size_t)cp * cp * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(gbeta, 0, (size_t)cp * sizeof(float), st));
+    switch (cp / 32) {
+        case 1: return launch_gdn_b_t<1>(gn_ws32, z32, pixels, ggamma, gbeta, st);
+        case 2: return launch_gdn_b_t<2>(gn_ws32, z32, pixels, ggamma, gbeta, st);
+        case 3: return launch_gdn_b_t<3>(gn_ws32, z32, pixels, ggamma, gbeta, st);
+        case 4: return launch_gdn_b_t<4>(gn_ws32, z32, pixels, ggamma, gbeta, st);
+        case 5: return launch_gdn_b_t<5>(gn_ws32, z32, pixels, ggamma, gbeta, st);
+        default: return launch_gdn_b_t<6>(gn_ws32, z32, pixels, ggamma, gbeta, st);
+    }
+}
+
+int cae_t_fold_to_bf16(const float *gext32, int n, int h, int w, int pad, int cp, void *out16, void *stream) {
+    if (!gext32 || !out16) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 1 || w < 1 || pad < 0 || cp % 32) return fail(CAE_ERR_ARG, "bad shape");
+    hipLaunchKernelGGL(fold_to_bf16_kernel, dim3(ew_grid((size_t)n * h * w * cp)), dim3(256), 0, (hipStream_t)stream,
+                       FoldSrc{gext32, h, w, pad}, (__bf16 *)out16, n, cp);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_t_colsum(const void *g16, long pixels, int cp, float *out, void *stream) {
+    if (!g16 || !out) return fail(CAE_ERR_ARG, "NULL argument");
+    if (pixels < 1 || cp % 32 || cp > 256) return fail(CAE_ERR_ARG, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)cp * sizeof(float), st));
+    const int threads = (256 / cp) * cp;
+    const long rows = 256 / cp;
+    const unsigned grid = (unsigned)std::min<long>(std::max<long>((pixels + rows - 1) / rows, 1), 1024);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(grid), dim3(threads), 0, st, (const __bf16 *)g16, pixels, cp, out);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+}  // extern "C"

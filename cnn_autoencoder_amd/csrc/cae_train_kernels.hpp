@@ -1,0 +1,591 @@
+// CDNA4 (gfx950) kernels of the TRAINING path (BASELINE config 5: bf16 convolutions, fp32 GDN).
+//
+// Reference semantics (file:line under /root/reference/src): the forward of DownsamplingUnit / UpsamplingUnit
+// (models/tasks/_autoencoders.py:78-85, :204-211) and compressai's GDN (:29-30) under autograd, i.e. what
+// `loss.backward()` of train_cae_ms.py:214 differentiates: convolution data / weight gradients and the GDN gradient.
+//
+// Layout "T": activations and gradients are channels-last, [N][H][W][Cp] with Cp = channels padded to 32 (zeros):
+// bf16 for everything an MFMA consumes (activations into a convolution, gradients into dgrad / wgrad), fp32 for the
+// convolution outputs the GDN reads and for gradients on their way into the GDN backward.  A pixel's channels are
+// contiguous, so (i) a 16-channel MFMA k-step of a pixel is one 16-byte LDS read, (ii) an accumulator tile with the
+// output channels on the lanes stores whole 128-byte rows, (iii) the weight gradient -- a contraction over PIXELS --
+// reads its operands with the transposing LDS read ds_read_b64_tr_b16.
+//
+// Three MFMA kernels cover the six convolution products of a stride-2 layer and its transpose:
+//   gather_gemm   out[pos][n] = sum_{tap, k} in[S pos + d_tap][k] W[tap][k][n]       v_mfma_f32_32x32x16_bf16
+//                 S = 2: strided correlation      -> conv forward (reflect padding), deconv data gradient (zero padding)
+//                 S = 1, one launch per output parity: its transpose
+//                                                 -> deconv forward (cropped), conv data gradient (extended domain,
+//                                                    the reflect fold is done by the consumer: fold_read)
+//   wgrad         gW[tap][a][b] = sum_pos X[2 pos + d_tap][a] Y[pos][b]              (both operands transposed reads)
+//   gdn_gemm_a / gdn_gemm_b   the C x C contractions of GDN / IGDN forward and backward, exact fp32
+//                 (v_mfma_f32_32x32x2_f32), with the element-wise parts fused as prologue / epilogue.
+#pragma once
+#include "cae_kernels.hpp"
+
+namespace cae {
+namespace tr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MAX_TAPS = 25;
+
+// ---------------------------------------------------------------------------------------------------------------
+// weights -> MFMA B fragments, on the device (the weights change every optimiser step):
+//   packed[q][t][nt][s][lane][e] = W(k = 32q + 16s + 8(lane>>5) + e, n = 32nt + (lane&31), tap t)  as bf16,
+//   W(k, n, t) = w[k * sk + n * sn + t]  (a (cout,cin,k,k) or (cin,cout,k,k) tensor read with either dim contracted)
+// ---------------------------------------------------------------------------------------------------------------
+static __global__ void pack_weights_kernel(const float *w, __bf16 *out, int Kc, int Nc, int kk, long sk, long sn,
+                                           int kchunks, int NT) {
+    const size_t total = (size_t)kchunks * kk * NT * 2 * 512;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), s = (int)((i >> 9) & 1);
+        size_t r = i >> 10;
+        const int nt = (int)(r % NT);
+        r /= NT;
+        const int t = (int)(r % kk);
+        const int q = (int)(r / kk);
+        const int n = 32 * nt + (lane & 31), k = 32 * q + 16 * s + 8 * (lane >> 5) + e;
+        out[i] = (__bf16)((k < Kc && n < Nc) ? w[(size_t)k * sk + (size_t)n * sn + t] : 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gather_gemm
+//   block = 4 waves, 16 x 16 logical positions; wave w: rows 4w .. 4w+3 = two m-tiles of 2 rows x 16 columns.
+//   per 32-channel chunk of the contraction: halo [quarter][row][col] x 16 B in LDS (LDS-DMA, padding resolved in
+//   the source address), weights of `taps_per_stage` taps at a time.
+// ---------------------------------------------------------------------------------------------------------------
+struct GGArgs {
+    const void *in;     // bf16 [N][IH][IW][Ck]
+    float *out32;       // fp32 [N][OH][OW][Cn] or null
+    void *out16;        // bf16 [N][OH][OW][Cn] or null
+    const void *wp;     // packed weights
+    const float *bias;  // [Cn] or null
+    const void *zero;   // >= 16 B of zeros
+    int N, IH, IW, Ck, Cn, OH, OW;
+    int LH, LW;         // logical position grid
+    int S;              // input pixel of position (i, j) and tap t: (S i + dy[t], S j + dx[t])
+    int SO, oy0, ox0;   // output pixel of position (i, j): (SO i + oy0, SO j + ox0)
+    int reflect;        // 1: reflect padding of the input, 0: zeros outside
+    int ntaps, ktaps;   // taps of this launch, taps of the packed weights (KS * KS)
+    int dymin, dxmin, HR, HC;
+    int taps_per_stage;
+    int tiles_x, tiles_y;
+    short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
+};
+
+template <int NT>
+__global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n = bid / p.tiles_y;
+    const int i0 = ty * 16, j0 = tx * 16;
+
+    const int plane = p.HR * p.HC;  // pieces per quarter
+    const int pieces = 4 * plane;
+    const int halo_instr = (pieces + 63) / 64;
+    char *halo = smem;
+    char *wbuf = smem + (size_t)halo_instr * 1024;
+    const char *in_n = (const char *)p.in + (size_t)n * p.IH * p.IW * p.Ck * 2;
+
+    // this thread's halo pieces (same for every chunk): byte offset inside the sample, or -1 = zeros
+    constexpr int MAXP = 20;  // ceil(4 * 35 * 35 / 64 / 4)
+    long hoff[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        int pc = (wave + i * 4) * 64 + lane;
+        pc = pc < pieces ? pc : pieces - 1;
+        const int quarter = pc / plane;
+        const int rem = pc - quarter * plane;
+        const int r = rem / p.HC, c = rem - r * p.HC;
+        int iy = p.S * i0 + p.dymin + r, ix = p.S * j0 + p.dxmin + c;
+        bool ok = true;
+        if (p.reflect) {
+            iy = reflect_idx(iy, p.IH);
+            ix = reflect_idx(ix, p.IW);
+        } else {
+            ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        }
+        hoff[i] = ok ? ((long)iy * p.IW + ix) * p.Ck * 2 + quarter * 16 : -1;
+    }
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float b = p.bias ? p.bias[32 * nt + m] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[0][nt][r] = b;
+            acc[1][nt][r] = b;
+        }
+    }
+
+    // A operand of m-tile pt: position (4w + 2pt + (m>>4), m&15)
+    const int arow = p.S * (4 * wave + (m >> 4)), acol = p.S * (m & 15);
+    const int chunks = p.Ck / 32;
+    for (int q = 0; q < chunks; ++q) {
+        __syncthreads();  // the previous chunk's reads of the halo are done
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int j = wave + i * 4;
+            if (j < halo_instr) {
+                const void *src = hoff[i] >= 0 ? (const void *)(in_n + hoff[i] + q * 64) : p.zero;
+                glds16(src, halo + j * 1024);
+            }
+        }
+        for (int t0 = 0; t0 < p.ntaps; t0 += p.taps_per_stage) {
+            const int nst = min(p.taps_per_stage, p.ntaps - t0);
+            if (t0 > 0) __syncthreads();  // the previous stage's reads of the weights are done
+            const int w_instr = nst * NT * 2;
+            for (int f = wave; f < w_instr; f += 4) {
+                const int tl = f / (NT * 2), rest = f - tl * (NT * 2);
+                const char *src = (const char *)p.wp +
+                                  (((size_t)q * p.ktaps + p.wt[t0 + tl]) * (NT * 2) + rest) * 1024 + lane * 16;
+                glds16(src, wbuf + f * 1024);
+            }
+            wait_vm0();
+            __syncthreads();
+            for (int tl = 0; tl < nst; ++tl) {
+                const int t = t0 + tl;
+                const int hr = arow + p.dy[t] - p.dymin, hc = acol + p.dx[t] - p.dxmin;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const char *ab = halo + ((((2 * s + h) * p.HR + hr) * p.HC + hc) * 16);
+                    const bf16x8 a0 = *(const bf16x8 *)ab;
+                    const bf16x8 a1 = *(const bf16x8 *)(ab + 2 * p.S * p.HC * 16);  // m-tile 1: two rows down
+                    const char *wb = wbuf + ((tl * NT) * 2 + s) * 1024 + lane * 16;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bf16x8 b = *(const bf16x8 *)(wb + nt * 2048);
+                        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0][nt], 0, 0, 0);
+                        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // D: lane = output channel 32nt + m, register r = position acc_row(r) + 4h of the m-tile
+    static_for<2>([&](auto pt_tag) {
+        constexpr int pt = decltype(pt_tag)::value;
+        static_for<16>([&](auto r_tag) {
+            constexpr int r = decltype(r_tag)::value;
+            const int mp = acc_row(r) + 4 * h;
+            const int li = i0 + 4 * wave + 2 * pt + (mp >> 4), lj = j0 + (mp & 15);
+            const int oy = p.SO * li + p.oy0, ox = p.SO * lj + p.ox0;
+            if (li < p.LH && lj < p.LW && oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
+                const size_t base = (((size_t)n * p.OH + oy) * p.OW + ox) * p.Cn + m;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float v = acc[pt][nt][r];
+                    if (p.out32) p.out32[base + 32 * nt] = v;
+                    if (p.out16) ((__bf16 *)p.out16)[base + 32 * nt] = (__bf16)v;
+                }
+            }
+        });
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad:  gW[tap][a][b] += sum over positions (n, i, j) of X[n][2i + dy][2j + dx][a] * Y[n][i][j][b]
+//   block = 4 waves; one 32-channel a-tile, <= 9 taps, every b-tile (wave w: b-tiles w, w + 4, ...);
+//   walks position tiles of 8 x 16 (K = 128), X halo and Y tile pixel-major in LDS, operands by ds_read_b64_tr_b16;
+//   partial sums stay in registers over the block's whole position range, one atomic flush at the end.
+// ---------------------------------------------------------------------------------------------------------------
+struct WGArgs {
+    const void *x;     // bf16 [N][H][W][Ca]   (the stride-2-sampled tensor)
+    const void *y;     // bf16 [N][OH][OW][Cb]
+    float *gw;         // fp32 [kk][Ca][Cb], zeroed by the caller
+    const void *zero;
+    int N, H, W, Ca, OH, OW, Cb;
+    int reflect;       // padding of X: 1 reflect, 0 zeros
+    int kk;            // taps of the layer
+    int dymin, dxmin, HR, HC;
+    int tiles_x, tiles_y, total_tiles;
+    short dy[MAX_TAPS], dx[MAX_TAPS];
+};
+
+template <int NB>  // b-tiles per wave
+__global__ void __launch_bounds__(256, 1) wgrad_kernel(const WGArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int at = blockIdx.y;
+    const int tap0 = blockIdx.z * 9;
+    const int ntaps = min(9, p.kk - tap0);
+    const int nbt = p.Cb / 32;
+
+    const int x_pieces = p.HR * p.HC * 4;  // pixel-major: 4 x 16 B per pixel (32 channels of the a-tile)
+    const int x_instr = (x_pieces + 63) / 64;
+    const int ypp = p.Cb / 8;              // 16-byte pieces per position
+    const int y_pieces = 128 * ypp;
+    const int y_instr = (y_pieces + 63) / 64;
+    char *xbuf = smem;
+    char *ybuf = smem + (size_t)x_instr * 1024;
+
+    f32x16 acc[9][NB];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.0f;
+
+    // transposed reads: 16-lane group g: channel half g&1, k-group g>>1; lane 4q+pp of the group addresses row q
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+    const int col_off = (16 * (g & 1) + 4 * pp) * 2;  // bytes inside a 32-channel record
+
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+        int rem = tile;
+        const int tx = rem % p.tiles_x;
+        rem /= p.tiles_x;
+        const int ty = rem % p.tiles_y;
+        const int n = rem / p.tiles_y;
+        const int i0 = ty * 8, j0 = tx * 16;
+        __syncthreads();  // the previous tile's reads are done
+        const char *x_n = (const char *)p.x + (size_t)n * p.H * p.W * p.Ca * 2;
+        for (int j = wave; j < x_instr; j += 4) {
+            int pc = j * 64 + lane;
+            pc = pc < x_pieces ? pc : x_pieces - 1;
+            const int pix = pc >> 2, quarter = pc & 3;
+            const int r = pix / p.HC, c = pix - r * p.HC;
+            int iy = 2 * i0 + p.dymin + r, ix = 2 * j0 + p.dxmin + c;
+            bool ok = true;
+            if (p.reflect) {
+                iy = reflect_idx(iy, p.H);
+                ix = reflect_idx(ix, p.W);
+            } else {
+                ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            }
+            const void *src = ok ? (const void *)(x_n + (((size_t)iy * p.W + ix) * p.Ca + 32 * at) * 2 + quarter * 16)
+                                 : p.zero;
+            glds16(src, xbuf + j * 1024);
+        }
+        const char *y_n = (const char *)p.y + (size_t)n * p.OH * p.OW * p.Cb * 2;
+        for (int j = wave; j < y_instr; j += 4) {
+            int pc = j * 64 + lane;
+            pc = pc < y_pieces ? pc : y_pieces - 1;
+            const int pos = pc / ypp, part = pc - pos * ypp;
+            const int i = i0 + (pos >> 4), jj = j0 + (pos & 15);
+            const bool ok = i < p.OH && jj < p.OW;  // positions outside contribute zero
+            const void *src = ok ? (const void *)(y_n + (((size_t)i * p.OW + jj) * p.Cb) * 2 + part * 16) : p.zero;
+            glds16(src, ybuf + j * 1024);
+        }
+        wait_vm0();
+        __syncthreads();
+#pragma unroll 1
+        for (int ks = 0; ks < 8; ++ks) {  // 16 positions: tile row ks, columns 0..15
+            // this lane's rows of the two 4-row blocks: columns 8(g>>1) + 4rr + q4
+            const int lj0 = 8 * (g >> 1) + q4, lj1 = lj0 + 4;
+            bf16x8 bfr[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int bt = wave + 4 * b;
+                const int btc = bt < nbt ? bt : 0;
+                const char *yb = ybuf + (size_t)(16 * ks) * p.Cb * 2 + 64 * btc + col_off;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)(yb + (size_t)lj0 * p.Cb * 2));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)(yb + (size_t)lj1 * p.Cb * 2));
+                const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bfr[b] = __builtin_bit_cast(bf16x8, v);
+            }
+            static_for<9>([&](auto t_tag) {
+                constexpr int t = decltype(t_tag)::value;
+                if (t < ntaps) {
+                    const int hr = 2 * ks + p.dy[tap0 + t] - p.dymin;
+                    const int hc = p.dx[tap0 + t] - p.dxmin;
+                    const char *xb = xbuf + (size_t)(hr * p.HC + hc) * 64 + col_off;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(xb + 2 * lj0 * 64));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(xb + 2 * lj1 * 64));
+                    const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+                        acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[b], acc[t][b], 0, 0, 0);
+                }
+            });
+        }
+    }
+
+    // D: register r = a-channel acc_row(r) + 4h of the a-tile, lane = b-channel
+    const int h = lane >> 5, m = lane & 31;
+    static_for<9>([&](auto t_tag) {
+        constexpr int t = decltype(t_tag)::value;
+        if (t < ntaps) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int bt = wave + 4 * b;
+                if (bt < nbt) {
+                    static_for<16>([&](auto r_tag) {
+                        constexpr int r = decltype(r_tag)::value;
+                        const int a = 32 * at + acc_row(r) + 4 * h;
+                        atomicAdd(p.gw + ((size_t)(tap0 + t) * p.Ca + a) * p.Cb + 32 * bt + m, acc[t][b][r]);
+                    });
+                }
+            }
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Reflect fold of a data gradient computed on the extended domain [-P, H + P) x [-P, W + P): the gradient of
+// `reflect pad, then valid convolution` (nn.Conv2d(padding_mode='reflect'), _autoencoders.py:78-85) with respect to
+// the unpadded input adds the border of the padded gradient back onto its mirror pixels.  P = 0: plain read.
+// ---------------------------------------------------------------------------------------------------------------
+struct FoldSrc {
+    const float *g;  // fp32 [N][H + 2P][W + 2P][C]
+    int H, W, P;
+};
+
+__device__ __forceinline__ float fold_read(const FoldSrc &f, int n, int y, int x, int C, int c) {
+    const int HP = f.H + 2 * f.P, WP = f.W + 2 * f.P;
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y;
+    if (y >= 1 && y <= f.P) ys[ny++] = -y;
+    if (y <= f.H - 2 && y >= f.H - 1 - f.P) ys[ny++] = 2 * (f.H - 1) - y;
+    xs[nx++] = x;
+    if (x >= 1 && x <= f.P) xs[nx++] = -x;
+    if (x <= f.W - 2 && x >= f.W - 1 - f.P) xs[nx++] = 2 * (f.W - 1) - x;
+    float s = 0.0f;
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b)
+            s += f.g[(((size_t)n * HP + ys[a] + f.P) * WP + xs[b] + f.P) * C + c];
+    return s;
+}
+
+// folded gradient -> bf16 T layout (layers without GDN between two convolutions)
+static __global__ void fold_to_bf16_kernel(FoldSrc f, __bf16 *out, int N, int C) {
+    const size_t total = (size_t)N * f.H * f.W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int x = (int)(r % f.W);
+        r /= f.W;
+        const int y = (int)(r % f.H);
+        const int n = (int)(r / f.H);
+        out[i] = (__bf16)fold_read(f, n, y, x, C, c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GDN / IGDN, exact fp32.   n[pix][c] = beta[c] + sum_j gamma[c][j] z[pix][j]^2 ;  y = z * n^(-1/2)  (IGDN: n^(1/2))
+//
+// gdn_gemm_a:  D[pix][c] = (beta[c]) + sum_j f(A[pix][j]) M[c][j]   with M (C x C, row-major) resident in LDS
+//   block = 4 waves x 64 pixels; A fragments straight from HBM (16 B per lane = 4 MFMA k-steps: lane half h carries
+//   j = 8q + 4h .. + 3); D has the channel on the lane and pixels in the registers -> every epilogue access is a
+//   128-byte row.
+//   MODE 0  forward:     f = square; y = z * rsqrt(D) (sqrt) -> y16 (and y32)
+//   MODE 1  backward 1:  f = square; from g_y (fold_read): g_n = -(1/2) g_y z D^(-3/2)  (IGDN: +(1/2) g_y z D^(-1/2))
+//                        -> gn32;  direct term g_y D^(-1/2) (IGDN: g_y D^(1/2)) -> gzd32
+//   MODE 2  backward 2:  f = identity on A = g_n, M = gamma^T: t[pix][j] = sum_c g_n[c] gamma[c][j];
+//                        g_z = gzd + 2 z t -> gz16 (and gz32)
+// ---------------------------------------------------------------------------------------------------------------
+struct GdnArgs {
+    const float *a;      // A operand, fp32 [pixels][C]
+    const float *mat;    // M, fp32 [C][C]
+    const float *beta;   // [C] or null (MODE 2)
+    const float *z;      // fp32 [pixels][C]
+    FoldSrc gy;          // MODE 1
+    int img_h, img_w;    // MODE 1: pixel index -> (n, y, x)
+    float *o32a;         // MODE 0: y32 | MODE 1: gn32 | MODE 2: gz32   (may be null)
+    float *o32b;         // MODE 1: gzd32 | MODE 2 (input): gzd32
+    void *o16;           // MODE 0: y16 | MODE 2: gz16  (may be null)
+    long pixels;
+    int C, inverse;
+};
+
+template <int CT, int MODE>
+__global__ void __launch_bounds__(256, 1) gdn_gemm_a_kernel(const GdnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int C = CT * 32, LD = C + 4;
+    float *mlds = (float *)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    for (int i = threadIdx.x; i < C * C / 4; i += 256) {
+        const int r = i / (C / 4), c4 = i - r * (C / 4);
+        *(f32x4 *)(mlds + r * LD + 4 * c4) = *(const f32x4 *)(p.mat + (size_t)r * C + 4 * c4);
+    }
+    __syncthreads();
+
+    const long tiles = (p.pixels + 255) / 256;
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long p0 = tile * 256 + wave * 64;
+        f32x16 acc[2][CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float b = (MODE != 2 && p.beta) ? p.beta[32 * ct + m] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[0][ct][r] = b;
+                acc[1][ct][r] = b;
+            }
+        }
+        long pa0 = p0 + m, pa1 = p0 + 32 + m;
+        pa0 = pa0 < p.pixels ? pa0 : p.pixels - 1;  // clamped rows are computed and never stored
+        pa1 = pa1 < p.pixels ? pa1 : p.pixels - 1;
+        const float *a0 = p.a + pa0 * C + 4 * h, *a1 = p.a + pa1 * C + 4 * h;
+#pragma unroll 2
+        for (int q = 0; q < C / 8; ++q) {
+            f32x4 v0 = *(const f32x4 *)(a0 + 8 * q), v1 = *(const f32x4 *)(a1 + 8 * q);
+            if (MODE != 2) {
+                v0 *= v0;
+                v1 *= v1;
+            }
+            f32x4 mf[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) mf[ct] = *(const f32x4 *)(mlds + (32 * ct + m) * LD + 8 * q + 4 * h);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[s], mf[ct][s], acc[0][ct], 0, 0, 0);
+                    acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[s], mf[ct][s], acc[1][ct], 0, 0, 0);
+                }
+        }
+        static_for<2>([&](auto pt_tag) {
+            constexpr int pt = decltype(pt_tag)::value;
+            static_for<16>([&](auto r_tag) {
+                constexpr int r = decltype(r_tag)::value;
+                const long pix = p0 + 32 * pt + acc_row(r) + 4 * h;
+                if (pix < p.pixels) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const int c = 32 * ct + m;
+                        const size_t off = (size_t)pix * C + c;
+                        const float d = acc[pt][ct][r];
+                        if (MODE == 0) {
+                            const float y = p.z[off] * (p.inverse ? __builtin_sqrtf(d) : 1.0f / __builtin_sqrtf(d));
+                            if (p.o32a) p.o32a[off] = y;
+                            if (p.o16) ((__bf16 *)p.o16)[off] = (__bf16)y;
+                        } else if (MODE == 1) {
+                            const long hw = (long)p.img_h * p.img_w;
+                            const int nimg = (int)(pix / hw);
+                            const int rem = (int)(pix - nimg * hw);
+                            const float gy = fold_read(p.gy, nimg, rem / p.img_w, rem % p.img_w, C, c);
+                            const float zz = p.z[off];
+                            const float sq = __builtin_sqrtf(d);
+                            float gn, gd;
+                            if (p.inverse) {
+                                gd = gy * sq;
+                                gn = 0.5f * gy * zz / sq;
+                            } else {
+                                const float rs = 1.0f / sq;
+                                gd = gy * rs;
+                                gn = -0.5f * gy * zz * rs / d;
+                            }
+                            p.o32a[off] = gn;
+                            p.o32b[off] = gd;
+                        } else {
+                            const float gz = p.o32b[off] + 2.0f * p.z[off] * d;
+                            if (p.o32a) p.o32a[off] = gz;
+                            if (p.o16) ((__bf16 *)p.o16)[off] = (__bf16)gz;
+                        }
+                    }
+                }
+            });
+        });
+    }
+}
+
+// gdn_gemm_b: parameter gradients, a contraction over pixels.
+//   g_gamma[c][j] += sum_pix g_n[pix][c] z[pix][j]^2 ;  g_beta[c] += sum_pix g_n[pix][c]
+//   block = CT waves (wave w: channel tile c = 32w ..), each wave all j-tiles; 2 pixels per MFMA k-step, operands are
+//   coalesced 128-byte row reads straight from HBM; one atomic flush per block.
+template <int CT>
+__global__ void __launch_bounds__(CT * 64, 1) gdn_gemm_b_kernel(const float *gn, const float *z, long pixels, float *ggamma,
+                                                                float *gbeta) {
+    constexpr int C = CT * 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    f32x16 acc[CT];
+#pragma unroll
+    for (int jt = 0; jt < CT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
+    float bsum = 0.0f;
+    const long per = (pixels + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per, hi = lo + per < pixels ? lo + per : pixels;
+    for (long p0 = lo; p0 < hi; p0 += 8) {
+        float a[4], b[4][CT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long pix = p0 + 2 * u + h;
+            const bool ok = pix < hi;
+            const size_t off = (size_t)(ok ? pix : lo) * C;
+            a[u] = ok ? gn[off + 32 * wave + m] : 0.0f;
+#pragma unroll
+            for (int jt = 0; jt < CT; ++jt) {
+                const float v = z[off + 32 * jt + m];
+                b[u][jt] = v * v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bsum += a[u];
+#pragma unroll
+            for (int jt = 0; jt < CT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][jt], acc[jt], 0, 0, 0);
+        }
+    }
+    // D: register r = channel c = 32 wave + acc_row(r) + 4h, lane = j
+#pragma unroll
+    for (int jt = 0; jt < CT; ++jt)
+        static_for<16>([&](auto r_tag) {
+            constexpr int r = decltype(r_tag)::value;
+            atomicAdd(ggamma + (size_t)(32 * wave + acc_row(r) + 4 * h) * C + 32 * jt + m, acc[jt][r]);
+        });
+    atomicAdd(gbeta + 32 * wave + m, bsum);  // both lane halves add their pixels' share
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// layout conversions between the module boundary (NCHW fp32) and the T layout
+// ---------------------------------------------------------------------------------------------------------------
+static __global__ void nchw_to_t_kernel(const float *in, __bf16 *o16, float *o32, int N, int C, int H, int W, int Cp) {
+    const size_t total = (size_t)N * H * W * Cp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        const size_t pix = i / Cp;
+        const size_t hw = (size_t)H * W;
+        const size_t n = pix / hw, r = pix - n * hw;
+        const float v = c < C ? in[(n * C + c) * hw + r] : 0.0f;
+        if (o16) o16[i] = (__bf16)v;
+        if (o32) o32[i] = v;
+    }
+}
+
+static __global__ void t_to_nchw_kernel(const float *in, float *out, int N, int C, int H, int W, int Cp) {
+    const size_t hw = (size_t)H * W, total = (size_t)N * C * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i % hw;
+        const size_t nc = i / hw;
+        const int c = (int)(nc % C);
+        const size_t n = nc / C;
+        out[i] = in[(n * hw + r) * Cp + c];
+    }
+}
+
+// column sums of a bf16 T tensor (bias gradient): out[c] += sum_pix g[pix][c]
+static __global__ void colsum_bf16_kernel(const __bf16 *g, long pixels, int C, float *out) {
+    const int c = threadIdx.x % C;
+    const int rows_per_block = blockDim.x / C;
+    float s = 0.0f;
+    for (long pix = (long)blockIdx.x * rows_per_block + threadIdx.x / C; pix < pixels; pix += (long)gridDim.x * rows_per_block)
+        s += (float)g[(size_t)pix * C + c];
+    if (threadIdx.x < rows_per_block * C) atomicAdd(out + c, s);
+}
+
+}  // namespace tr
+}  // namespace cae

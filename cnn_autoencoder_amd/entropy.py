@@ -167,7 +167,12 @@ class EntropyBottleneck(nn.Module):
         shape = x.size()
         values = x.reshape(x.size(0), 1, -1)
         if training:
-            outputs = values + torch.empty_like(values).uniform_(-0.5, 0.5)
+            # additive uniform noise (train mode, _taskutils.py:97); `fixed_noise` (same layout as the input) makes a
+            # step reproducible for the parity tests
+            fixed = getattr(self, 'fixed_noise', None)
+            noise = (fixed.to(values).permute(*perm).reshape(values.shape) if fixed is not None
+                     else torch.empty_like(values).uniform_(-0.5, 0.5))
+            outputs = values + noise
         else:
             medians = self._get_medians()
             outputs = torch.round(values - medians) + medians

@@ -558,6 +558,9 @@ class Analyzer(_Track):
         dev = _lib.require_gpu()
         if x.dim() != 4 or x.size(1) != self._dims[0]:
             raise ValueError(f'expected (B,{self._dims[0]},H,W), got {tuple(x.shape)}')
+        from . import train
+        if train.needs_grad(self, x):  # autograd is recording: bf16 / fp32-GDN training kernels with HIP backward
+            return train.analysis_forward(self, x)
         x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
         return self._run(x.data_ptr(), _lib.FMT_F32_NCHW, x.size(0), x.size(2), x.size(3))
 
@@ -668,6 +671,11 @@ class Synthesizer(_Track):
     def forward(self, x: torch.Tensor, bridges: bool = True):
         """y_q (B,channels_bn,h,w) -> (x_r list [full-res, half-res | None, ...], fx_brg list) as the reference:
         x_r[0] is the reconstruction, x_r[j] the colour layer of level L-1-j (None without multiscale_analysis)."""
+        from . import train
+        if train.needs_grad(self, x):  # autograd is recording (training): see train.synthesis_forward
+            if x.dim() != 4 or x.size(1) != self._dims[2]:
+                raise ValueError(f'expected (B,{self._dims[2]},h,w), got {tuple(x.shape)}')
+            return train.synthesis_forward(self, x)
         out, brg, col = self._run(x, _lib.FMT_F32_NCHW, bridges, colors=True)
         x_r = [out] + (col[::-1] if col else [None] * (self._dims[3] - 1))
         return x_r, brg + [out]

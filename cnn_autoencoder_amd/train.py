@@ -1,0 +1,440 @@
+"""Training path on the HIP kernels (BASELINE config 5).
+
+What the reference's training step does (``src/train_cae_ms.py:189-262``) and where it lives here:
+
+* ``forward_func`` (``models/tasks/_taskutils.py:95-108``): encoder -> fact_ent (train mode: additive U(-1/2, 1/2)
+  noise) -> decoder.  ``Analyzer.forward`` / ``Synthesizer.forward`` switch to the differentiable track functions of
+  this module whenever autograd is recording: bf16 convolutions with fp32 accumulation
+  (``cae_t_conv_forward`` / ``cae_t_deconv_forward``), fp32 GDN / IGDN (``cae_t_gdn_forward``), and hand-written
+  backward kernels (data gradients, weight gradients, GDN gradient) instead of ATen / cuDNN autograd.
+* ``GeneralLoss`` (``models/criteria/_lossutils.py:54-109``): ``criteria.GeneralLoss`` (scalar reductions, torch ops).
+* compressai's ``NonNegativeParametrizer`` / ``LowerBound`` gradient rule of the GDN parameters: the kernels
+  differentiate with respect to the EFFECTIVE beta / gamma, the reparametrisation stays a torch autograd graph
+  (``modules.NonNegativeParametrizer``), so the rule (pass where ``p >= bound`` or ``grad < 0``) is applied exactly
+  once, on parameter-sized tensors.
+* ``setup_optim`` (``train_cae_ms.py:529-655``): one optimiser per trainable module, the ``quantiles`` of the entropy
+  model in a separate ``<module>_aux`` optimiser (:592-596); ``train_step`` = :209-230 (loss.backward, aux_loss.backward,
+  per-optimiser clip_grad_norm_(1.0), step, zero_grad).
+* ``nn.DataParallel``'s gradient reduction (``_autoencoders.py:517``): ``GradReducer``, bucketed all-reduce over
+  ``torch.distributed`` (RCCL over xGMI on GPUs, gloo on CPU), one process per GPU.
+
+Variants covered: ``act_layer_type in (None, 'GDN')`` units without residual branches, batch norm, groups or
+multiscale colour layers (the canonical model and its plain variant); anything else raises ``NotImplementedError``
+under autograd.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _pad32(c: int) -> int:
+    return (int(c) + 31) // 32 * 32
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _L():
+    return _lib.lib()
+
+
+def _st():
+    return _lib.stream_ptr()
+
+
+class LayerSpec:
+    """Static description of one unit for the track functions."""
+
+    def __init__(self, cin: int, cout: int, ks: int, has_bias: bool, has_gdn: bool):
+        self.cin, self.cout, self.ks = int(cin), int(cout), int(ks)
+        self.cin_p, self.cout_p = _pad32(cin), _pad32(cout)
+        self.has_bias, self.has_gdn = bool(has_bias), bool(has_gdn)
+
+    @property
+    def n_tensors(self) -> int:
+        return 1 + int(self.has_bias) + 2 * int(self.has_gdn)
+
+
+def _pack(weight: torch.Tensor, contract_dim: int, ks: int) -> torch.Tensor:
+    """fp32 (d0, d1, k, k) -> bf16 MFMA B fragments on the device (cae_t_pack_weights)."""
+    d0, d1 = weight.shape[0], weight.shape[1]
+    kc, nc = (d0, d1) if contract_dim == 0 else (d1, d0)
+    nbytes = _L().cae_t_packed_bytes(kc, nc, ks)
+    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=weight.device)
+    w = weight.detach().float().contiguous()
+    _lib.check(_L().cae_t_pack_weights(w.data_ptr(), d0, d1, ks, contract_dim, out.data_ptr(), _st()))
+    return out
+
+
+def _split_params(specs: Sequence[LayerSpec], tensors: Sequence[torch.Tensor]):
+    out, k = [], 0
+    for s in specs:
+        w = tensors[k]
+        k += 1
+        b = beta = gamma = None
+        if s.has_bias:
+            b = tensors[k]
+            k += 1
+        if s.has_gdn:
+            beta, gamma = tensors[k], tensors[k + 1]
+            k += 2
+        out.append((w, b, beta, gamma))
+    return out
+
+
+def _from_nchw(x: torch.Tensor, cp: int, want16=True, want32=False):
+    n, c, h, w = x.shape
+    x = x.detach().float().contiguous()
+    o16 = torch.empty((n, h, w, cp), dtype=torch.bfloat16, device=x.device) if want16 else None
+    o32 = torch.empty((n, h, w, cp), dtype=torch.float32, device=x.device) if want32 else None
+    _lib.check(_L().cae_t_from_nchw(x.data_ptr(), n, c, h, w, cp, _ptr(o16), _ptr(o32), _st()))
+    return o16, o32
+
+
+def _to_nchw(t32: torch.Tensor, c: int) -> torch.Tensor:
+    n, h, w, cp = t32.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=t32.device)
+    _lib.check(_L().cae_t_to_nchw(t32.data_ptr(), n, c, h, w, cp, out.data_ptr(), _st()))
+    return out
+
+
+def _gdn_forward(z32: torch.Tensor, beta_p: torch.Tensor, gamma_p: torch.Tensor, inverse: bool) -> torch.Tensor:
+    n, h, w, cp = z32.shape
+    y16 = torch.empty_like(z32, dtype=torch.bfloat16)
+    beta, gamma = beta_p.detach().float().contiguous(), gamma_p.detach().float().contiguous()  # (alive across the call)
+    _lib.check(_L().cae_t_gdn_forward(z32.data_ptr(), n * h * w, cp, beta.data_ptr(), gamma.data_ptr(), int(inverse),
+                                      None, y16.data_ptr(), _st()))
+    return y16
+
+
+def _gdn_backward(z32, gext32, pad, beta_p, gamma_p, inverse):
+    """-> (gz16, g_beta_p, g_gamma_p)"""
+    n, h, w, cp = z32.shape
+    dev = z32.device
+    gn = torch.empty_like(z32)
+    gzd = torch.empty_like(z32)
+    gz16 = torch.empty_like(z32, dtype=torch.bfloat16)
+    gg = torch.empty((cp, cp), dtype=torch.float32, device=dev)
+    gb = torch.empty((cp,), dtype=torch.float32, device=dev)
+    gamma = gamma_p.detach().float().contiguous()
+    gamma_t = gamma.t().contiguous()
+    beta = beta_p.detach().float().contiguous()
+    _lib.check(_L().cae_t_gdn_backward(z32.data_ptr(), gext32.data_ptr(), n, h, w, pad, cp,
+                                       beta.data_ptr(), gamma.data_ptr(), gamma_t.data_ptr(),
+                                       int(inverse), gn.data_ptr(), gzd.data_ptr(), None, gz16.data_ptr(), gg.data_ptr(),
+                                       gb.data_ptr(), _st()))
+    return gz16, gb, gg
+
+
+def _weight_grad(gw: torch.Tensor, spec_shape: Tuple[int, int], ks: int) -> torch.Tensor:
+    """gw [k*k][ca][cb] -> gradient of a (d0 = b, d1 = a, k, k) weight"""
+    d0, d1 = spec_shape
+    return gw.permute(2, 1, 0)[:d0, :d1].reshape(d0, d1, ks, ks).contiguous()
+
+
+class AnalysisFn(torch.autograd.Function):
+    """Analyzer.forward under autograd: L x [reflect conv s2 (+bias) (+GDN)] (_autoencoders.py:78-85, :29-30)."""
+
+    @staticmethod
+    def forward(ctx, x, specs, *tensors):
+        L = _L()
+        layers = _split_params(specs, tensors)
+        n, _, h, w = x.shape
+        a16, _ = _from_nchw(x, specs[0].cin_p)
+        saved, dims = [], []
+        z32 = None
+        for i, (s, (wt, b, beta, gamma)) in enumerate(zip(specs, layers)):
+            last = i == len(specs) - 1
+            oh, ow = (h + 1) // 2, (w + 1) // 2
+            wp = _pack(wt, 1, s.ks)
+            bias_p = None
+            if b is not None:
+                bias_p = torch.zeros(s.cout_p, dtype=torch.float32, device=x.device)
+                bias_p[:s.cout] = b.detach().float()
+            need32 = s.has_gdn or last
+            z32 = torch.empty((n, oh, ow, s.cout_p), dtype=torch.float32, device=x.device) if need32 else None
+            z16 = None if need32 else torch.empty((n, oh, ow, s.cout_p), dtype=torch.bfloat16, device=x.device)
+            _lib.check(L.cae_t_conv_forward(a16.data_ptr(), n, h, w, s.cin_p, wp.data_ptr(), s.ks, _ptr(z32), _ptr(z16),
+                                            s.cout_p, _ptr(bias_p), _st()))
+            saved.append((a16, z32 if s.has_gdn else None))
+            dims.append((h, w, oh, ow))
+            if s.has_gdn:
+                a16 = _gdn_forward(z32, beta, gamma, False)
+            elif not last:
+                a16 = z16
+            h, w = oh, ow
+        y = _to_nchw(z32, specs[-1].cout)
+        ctx.specs, ctx.saved, ctx.dims, ctx.layers = specs, saved, dims, [tuple(t.detach() if t is not None else None
+                                                                                 for t in l) for l in layers]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _L()
+        specs, saved, dims, layers = ctx.specs, ctx.saved, ctx.dims, ctx.layers
+        n = gy.shape[0]
+        dev = gy.device
+        g16, _ = _from_nchw(gy, specs[-1].cout_p)  # gradient with respect to the last convolution's output
+        per_layer = [[None, None, None, None] for _ in specs]
+        for i in reversed(range(len(specs))):
+            s = specs[i]
+            wt, b, _, _ = layers[i]
+            a16_in, _ = saved[i]
+            h, w, oh, ow = dims[i]
+            kk = s.ks * s.ks
+            gw = torch.empty((kk, s.cin_p, s.cout_p), dtype=torch.float32, device=dev)
+            _lib.check(L.cae_t_wgrad(a16_in.data_ptr(), n, h, w, s.cin_p, g16.data_ptr(), oh, ow, s.cout_p, s.ks, 1,
+                                     gw.data_ptr(), _st()))
+            per_layer[i][0] = _weight_grad(gw, (s.cout, s.cin), s.ks)
+            if b is not None:
+                gb = torch.empty(s.cout_p, dtype=torch.float32, device=dev)
+                _lib.check(L.cae_t_colsum(g16.data_ptr(), n * oh * ow, s.cout_p, gb.data_ptr(), _st()))
+                per_layer[i][1] = gb[:s.cout].clone()
+            if i == 0:
+                break  # (the image itself needs no gradient)
+            P = s.ks // 2
+            wp_d = _pack(wt, 0, s.ks)
+            gext = torch.empty((n, h + 2 * P, w + 2 * P, s.cin_p), dtype=torch.float32, device=dev)
+            _lib.check(L.cae_t_conv_dgrad_ext(g16.data_ptr(), n, oh, ow, s.cout_p, wp_d.data_ptr(), s.ks, h, w,
+                                              gext.data_ptr(), s.cin_p, _st()))
+            if specs[i - 1].has_gdn:
+                _, z_prev = saved[i - 1]
+                _, _, beta_p, gamma_p = layers[i - 1]
+                g16, g_beta, g_gamma = _gdn_backward(z_prev, gext, P, beta_p, gamma_p, False)
+                per_layer[i - 1][2], per_layer[i - 1][3] = g_beta, g_gamma
+            else:
+                g16 = torch.empty((n, h, w, s.cin_p), dtype=torch.bfloat16, device=dev)
+                _lib.check(L.cae_t_fold_to_bf16(gext.data_ptr(), n, h, w, P, s.cin_p, g16.data_ptr(), _st()))
+        out: List[Optional[torch.Tensor]] = []
+        for i, s in enumerate(specs):
+            g_w, g_b, g_beta, g_gamma = per_layer[i]
+            out.append(g_w)
+            if s.has_bias:
+                out.append(g_b)
+            if s.has_gdn:
+                out.extend([g_beta, g_gamma])
+        return (None, None, *out)
+
+
+class SynthesisFn(torch.autograd.Function):
+    """Synthesizer.forward under autograd: L x [conv-transpose s2 (+bias) (+IGDN)] (_autoencoders.py:204-211)."""
+
+    @staticmethod
+    def forward(ctx, yq, specs, *tensors):
+        L = _L()
+        layers = _split_params(specs, tensors)
+        n, _, h, w = yq.shape
+        a16, _ = _from_nchw(yq, specs[0].cin_p)
+        saved, dims = [], []
+        z32 = None
+        for i, (s, (wt, b, beta, gamma)) in enumerate(zip(specs, layers)):
+            last = i == len(specs) - 1
+            wp = _pack(wt, 0, s.ks)
+            bias_p = None
+            if b is not None:
+                bias_p = torch.zeros(s.cout_p, dtype=torch.float32, device=yq.device)
+                bias_p[:s.cout] = b.detach().float()
+            need32 = s.has_gdn or last
+            z32 = torch.empty((n, 2 * h, 2 * w, s.cout_p), dtype=torch.float32, device=yq.device) if need32 else None
+            z16 = None if need32 else torch.empty((n, 2 * h, 2 * w, s.cout_p), dtype=torch.bfloat16, device=yq.device)
+            _lib.check(L.cae_t_deconv_forward(a16.data_ptr(), n, h, w, s.cin_p, wp.data_ptr(), s.ks, _ptr(z32), _ptr(z16),
+                                              s.cout_p, _ptr(bias_p), _st()))
+            saved.append((a16, z32 if s.has_gdn else None))
+            dims.append((h, w))
+            if s.has_gdn:
+                a16 = _gdn_forward(z32, beta, gamma, True)
+            elif not last:
+                a16 = z16
+            h, w = 2 * h, 2 * w
+        x_r = _to_nchw(z32, specs[-1].cout)
+        ctx.specs, ctx.saved, ctx.dims = specs, saved, dims
+        ctx.layers = [tuple(t.detach() if t is not None else None for t in l) for l in layers]
+        ctx.need_input_grad = yq.requires_grad
+        return x_r
+
+    @staticmethod
+    def backward(ctx, gx):
+        L = _L()
+        specs, saved, dims, layers = ctx.specs, ctx.saved, ctx.dims, ctx.layers
+        n = gx.shape[0]
+        dev = gx.device
+        g16, _ = _from_nchw(gx, specs[-1].cout_p)  # gradient with respect to the last layer's output
+        per_layer = [[None, None, None, None] for _ in specs]
+        g_in = None
+        for i in reversed(range(len(specs))):
+            s = specs[i]
+            wt, b, _, _ = layers[i]
+            a16_in, _ = saved[i]
+            h, w = dims[i]
+            kk = s.ks * s.ks
+            gw = torch.empty((kk, s.cout_p, s.cin_p), dtype=torch.float32, device=dev)
+            _lib.check(L.cae_t_wgrad(g16.data_ptr(), n, 2 * h, 2 * w, s.cout_p, a16_in.data_ptr(), h, w, s.cin_p, s.ks, 0,
+                                     gw.data_ptr(), _st()))
+            per_layer[i][0] = _weight_grad(gw, (s.cin, s.cout), s.ks)
+            if b is not None:
+                gb = torch.empty(s.cout_p, dtype=torch.float32, device=dev)
+                _lib.check(L.cae_t_colsum(g16.data_ptr(), n * 4 * h * w, s.cout_p, gb.data_ptr(), _st()))
+                per_layer[i][1] = gb[:s.cout].clone()
+            if i == 0 and not ctx.need_input_grad:
+                break
+            wp_d = _pack(wt, 1, s.ks)
+            prev_gdn = i > 0 and specs[i - 1].has_gdn
+            want32 = prev_gdn or i == 0
+            gx32 = torch.empty((n, h, w, s.cin_p), dtype=torch.float32, device=dev) if want32 else None
+            gx16 = None if want32 else torch.empty((n, h, w, s.cin_p), dtype=torch.bfloat16, device=dev)
+            _lib.check(L.cae_t_deconv_dgrad(g16.data_ptr(), n, h, w, s.cout_p, wp_d.data_ptr(), s.ks, _ptr(gx32), _ptr(gx16),
+                                            s.cin_p, _st()))
+            if i == 0:
+                g_in = _to_nchw(gx32, s.cin)
+            elif prev_gdn:
+                _, z_prev = saved[i - 1]
+                _, _, beta_p, gamma_p = layers[i - 1]
+                g16, g_beta, g_gamma = _gdn_backward(z_prev, gx32, 0, beta_p, gamma_p, True)
+                per_layer[i - 1][2], per_layer[i - 1][3] = g_beta, g_gamma
+            else:
+                g16 = gx16
+        out: List[Optional[torch.Tensor]] = []
+        for i, s in enumerate(specs):
+            g_w, g_b, g_beta, g_gamma = per_layer[i]
+            out.append(g_w)
+            if s.has_bias:
+                out.append(g_b)
+            if s.has_gdn:
+                out.extend([g_beta, g_gamma])
+        return (g_in, None, *out)
+
+
+def _track_inputs(track, units, synthesis: bool):
+    """-> (specs, flat tensor list) of a track; effective, padded GDN parameters stay in the autograd graph."""
+    from .modules import _ResidualUnit
+    specs, tensors = [], []
+    if getattr(track, 'multiscale_analysis', False):
+        raise NotImplementedError('training with multiscale colour layers is not built')
+    for u in units:
+        if isinstance(u, _ResidualUnit) or u.pre is not None or u.act_code:
+            raise NotImplementedError('training is built for GDN / activation-free units (no residual, LeakyReLU, ReLU)')
+        if u.main_bn_index is not None or u.main.groups != 1:
+            raise NotImplementedError('training with BatchNorm or grouped layers is not built')
+        conv = u.main
+        has_gdn = u.gdn is not None
+        specs.append(LayerSpec(conv.in_channels, conv.out_channels, conv.kernel_size, conv.bias is not None, has_gdn))
+        tensors.append(conv.weight)
+        if conv.bias is not None:
+            tensors.append(conv.bias)
+        if has_gdn:
+            g = u.gdn
+            c, cp = conv.out_channels, _pad32(conv.out_channels)
+            beta = g.beta_reparam(g.beta)      # LowerBound gradient rule inside (entropy._LowerBoundFn)
+            gamma = g.gamma_reparam(g.gamma)
+            beta_p = torch.cat([beta, beta.new_ones(cp - c)]) if cp > c else beta
+            gamma_p = torch.nn.functional.pad(gamma, (0, cp - c, 0, cp - c)) if cp > c else gamma
+            tensors.extend([beta_p, gamma_p])
+    return tuple(specs), tensors
+
+
+def needs_grad(module: nn.Module, x: torch.Tensor) -> bool:
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+
+
+def analysis_forward(track, x: torch.Tensor) -> torch.Tensor:
+    dev = _lib.require_gpu()
+    specs, tensors = _track_inputs(track, track._units(), False)
+    x = x.to(device=dev, dtype=torch.float32)
+    return AnalysisFn.apply(x, specs, *tensors)
+
+
+def synthesis_forward(track, yq: torch.Tensor):
+    dev = _lib.require_gpu()
+    specs, tensors = _track_inputs(track, track._units(), True)
+    yq = yq.to(device=dev, dtype=torch.float32)
+    out = SynthesisFn.apply(yq, specs, *tensors)
+    L = len(specs)
+    # (x_r list, fx_brg) as the reference's Synthesizer; intermediate features are not materialised while training
+    return [out] + [None] * (L - 1), [None] * (L - 1) + [out]
+
+
+# ---- optimisers and the training step (train_cae_ms.py) -----------------------------------------------------------
+
+def setup_optim(model: Dict[str, nn.Module], trainable_modules: Sequence[str] = ('encoder', 'decoder', 'fact_ent'),
+                learning_rate: float = 1e-4, aux_learning_rate: float = 1e-3, weight_decay: float = 0.0,
+                algo=torch.optim.Adam) -> Dict[str, torch.optim.Optimizer]:
+    """One optimiser per trainable module; parameters whose name contains 'quantiles' or 'aux' go to a separate
+    ``<module>_aux`` optimiser (train_cae_ms.py:584-641)."""
+    opts: Dict[str, torch.optim.Optimizer] = {}
+    for k in trainable_modules:
+        pars, aux = [], []
+        for name, par in model[k].named_parameters():
+            (aux if ('quantiles' in name.lower() or 'aux' in name.lower()) else pars).append(par)
+        opts[k] = algo([dict(params=pars, lr=learning_rate, weight_decay=weight_decay)])
+        if aux:
+            opts[k + '_aux'] = algo([dict(params=aux, lr=aux_learning_rate, weight_decay=weight_decay)])
+    return opts
+
+
+def train_step(x: torch.Tensor, model, criterion, optimizers, forward_func=None, reducer: 'GradReducer' = None):
+    """One iteration of the reference's hot loop (train_cae_ms.py:209-230).  -> loss_dict (detached scalars)"""
+    from .criteria import setup_forward_func
+    forward_func = forward_func or setup_forward_func()
+    output = forward_func(x, model)
+    loss_dict = criterion(inputs=x, outputs=output, net=model)
+    loss = torch.mean(loss_dict['loss'])
+    loss.backward()
+    if 'entropy_loss' in loss_dict:
+        torch.mean(loss_dict['entropy_loss']).backward()
+    if reducer is not None:
+        reducer.reduce()
+    for opt in optimizers.values():
+        nn.utils.clip_grad_norm_(opt.param_groups[0]['params'], max_norm=1.0)
+        opt.step()
+        opt.zero_grad()
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
+
+
+class GradReducer:
+    """Data-parallel gradient averaging, one process per GPU (replaces nn.DataParallel's reduce-add to device 0,
+    _autoencoders.py:517): the gradients of all parameters are packed into a few flat fp32 buckets and all-reduced
+    (RCCL over xGMI on GPUs, gloo in the CPU tests), then averaged and scattered back.  The model holds about
+    2 M parameters (8 MB), so one or two buckets per step: latency-bound, a single ring is enough."""
+
+    def __init__(self, params: Sequence[torch.Tensor], bucket_bytes: int = 16 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets: List[List[torch.Tensor]] = [[]]
+        size = 0
+        for p in self.params:
+            nbytes = p.numel() * 4
+            if size + nbytes > bucket_bytes and self.buckets[-1]:
+                self.buckets.append([])
+                size = 0
+            self.buckets[-1].append(p)
+            size += nbytes
+
+    @torch.no_grad()
+    def reduce(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        works = []
+        for bucket in self.buckets:
+            live = [p for p in bucket]
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in live])
+            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, live))
+        for work, flat, live in works:
+            work.wait()
+            flat.div_(world)
+            off = 0
+            for p in live:
+                n = p.numel()
+                g = flat[off:off + n].view_as(p).to(p.dtype)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n

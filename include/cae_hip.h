@@ -241,6 +241,52 @@ int cae_tile_sse(const uint8_t *a_dev, const uint8_t *b_dev, int n, size_t elems
 int cae_model_set_profiling(cae_model_t *m, int enable);
 int cae_model_get_profile(cae_model_t *m, int track, double *ms, int n_slots, int *calls, int reset);
 
+/* ---- training (BASELINE config 5: bf16 convolutions, fp32 GDN) ----------------------------
+ * What `loss.backward()` (train_cae_ms.py:214) differentiates on the reference: nn.Conv2d(reflect, stride 2) /
+ * nn.ConvTranspose2d(stride 2, output_padding 1) (_autoencoders.py:78-85, :204-211) and compressai GDN / IGDN (:29-30).
+ * Stateless launches on caller-owned device buffers.  Layout "T": channels-last [n][h][w][cp], cp = channels padded
+ * to a multiple of 32 (<= 192) with zeros; *16 = bf16, *32 = fp32.  Convolutions take bf16 operands and accumulate in
+ * fp32 (v_mfma_f32_32x32x16_bf16); GDN is exact fp32 (v_mfma_f32_32x32x2_f32).
+ * Packed weights: MFMA B fragments of a (dim0, dim1, k, k) fp32 tensor with dimension `contract_dim` contracted:
+ *   nn.Conv2d weight (cout, cin, k, k):          forward contracts dim 1, data gradient dim 0;
+ *   nn.ConvTranspose2d weight (cin, cout, k, k): forward contracts dim 0, data gradient dim 1. */
+size_t cae_t_packed_bytes(int contract_channels, int out_channels, int kernel_size);
+int cae_t_pack_weights(const float *w_dev, int dim0, int dim1, int kernel_size, int contract_dim, void *packed_dev, void *stream);
+int cae_t_from_nchw(const float *x_nchw_dev, int n, int c, int h, int w, int cp, void *out16, float *out32, void *stream);
+int cae_t_to_nchw(const float *t32, int n, int c, int h, int w, int cp, float *out_nchw_dev, void *stream);
+/* z = conv(x) (+bias): x16 [n][h][w][cin_p] -> z [n][ceil(h/2)][ceil(w/2)][cout_p] as fp32 and / or bf16 */
+int cae_t_conv_forward(const void *x16, int n, int h, int w, int cin_p, const void *packed, int kernel_size, float *z32,
+                       void *z16, int cout_p, const float *bias, void *stream);
+/* data gradient of that convolution on the EXTENDED domain: gext32 [n][h+2P][w+2P][cin_p], P = k//2, the gradient with
+ * respect to the reflect-PADDED input; its consumer folds the border back (cae_t_gdn_backward / cae_t_fold_to_bf16) */
+int cae_t_conv_dgrad_ext(const void *gz16, int n, int oh, int ow, int cout_p, const void *packed, int kernel_size, int h,
+                         int w, float *gext32, int cin_p, void *stream);
+/* z = conv_transpose(x) (+bias): x16 [n][h][w][cin_p] -> z [n][2h][2w][cout_p] */
+int cae_t_deconv_forward(const void *x16, int n, int h, int w, int cin_p, const void *packed, int kernel_size, float *z32,
+                         void *z16, int cout_p, const float *bias, void *stream);
+/* its data gradient: gz16 [n][2h][2w][cout_p] -> gx [n][h][w][cin_p] */
+int cae_t_deconv_dgrad(const void *gz16, int n, int h, int w, int cout_p, const void *packed, int kernel_size, float *gx32,
+                       void *gx16, int cin_p, void *stream);
+/* weight gradient of either layer: gw32 [k*k][ca][cb] = sum over positions of xbig[2 pos + tap - P][a] * ysmall[pos][b].
+ * conv: xbig = layer input (reflect = 1), ysmall = output gradient -> grad(cout,cin,k,k)[b][a][tap];
+ * conv_transpose: xbig = output gradient (reflect = 0), ysmall = layer input -> grad(cin,cout,k,k)[b][a][tap]. */
+int cae_t_wgrad(const void *xbig16, int n, int h, int w, int ca, const void *ysmall16, int oh, int ow, int cb,
+                int kernel_size, int reflect, float *gw32, void *stream);
+/* GDN / IGDN forward on effective parameters padded to cp (beta padding 1, gamma padding 0): y = z * rsqrt(beta +
+ * gamma z^2) (inverse: sqrt). */
+int cae_t_gdn_forward(const float *z32, long pixels, int cp, const float *beta, const float *gamma, int inverse, float *y32,
+                      void *y16, void *stream);
+/* GDN / IGDN backward.  gext32: gradient with respect to the layer output, fp32 [n][h+2 pad][w+2 pad][cp] (pad > 0: the
+ * extended-domain gradient of the next convolution, folded here; pad = 0: plain).  gamma_t = gamma transposed.
+ * Outputs: gz (bf16 and / or fp32) with respect to z, ggamma [cp][cp], gbeta [cp] with respect to the EFFECTIVE
+ * parameters (the reparametrisation and its LowerBound gradient rule live above the ABI); gn_ws32 / gzd_ws32: scratch,
+ * pixels * cp floats each. */
+int cae_t_gdn_backward(const float *z32, const float *gext32, int n, int h, int w, int pad, int cp, const float *beta,
+                       const float *gamma, const float *gamma_t, int inverse, float *gn_ws32, float *gzd_ws32, float *gz32,
+                       void *gz16, float *ggamma, float *gbeta, void *stream);
+int cae_t_fold_to_bf16(const float *gext32, int n, int h, int w, int pad, int cp, void *out16, void *stream);
+int cae_t_colsum(const void *g16, long pixels, int cp, float *out, void *stream); /* bias gradient */
+
 /* ---- host entropy coding ---------------------------------------------------------------
  * Replace compressai._CXX.pmf_to_quantized_cdf and compressai.ans.RansEncoder /
  * RansDecoder (encode_with_indexes / decode_with_indexes), reached from

@@ -1,0 +1,146 @@
+"""CPU restatement of the TRAINING step (test infrastructure only: tests/, smoke(), bench cpu_baseline).
+
+torch-CPU autograd of the restatement in cae_oracle.py, i.e. of what the reference differentiates
+(train_cae_ms.py:209-219: forward_func of models/tasks/_taskutils.py:95-108, GeneralLoss of
+models/criteria/_lossutils.py:54-109 with RateLoss / DistMSELoss of _ratedist.py:45-63), plus the two gradient rules
+that live in compressai and therefore are "parity unpinned" (SURVEY Appendix A.1 / A.2):
+  * LowerBound: forward max(x, bound); backward passes the gradient where x >= bound or gradient < 0;
+  * NonNegativeParametrizer: lower_bound(p, sqrt(minimum + pedestal))^2 - pedestal.
+The conv / conv-transpose parts are reference-pinned through cae_oracle (golden fixtures of the reference's own modules).
+
+`bf16=True` reproduces the ROUNDING POINTS of the HIP training path (BASELINE config 5: bf16 convolutions, fp32 GDN):
+activations and weights enter a convolution rounded to bf16, the gradient with respect to a convolution's output is
+rounded to bf16 before the data / weight gradients are formed; accumulation, GDN, losses stay fp32.  With it the only
+difference to the kernels is summation order; without it this is the plain fp32 reference.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import cae_oracle as O
+
+
+class LowerBoundFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x, bound)
+        return torch.max(x, bound)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bound = ctx.saved_tensors
+        return ((x >= bound) | (g < 0)).to(g.dtype) * g, None
+
+
+def lower_bound(x: torch.Tensor, bound: float) -> torch.Tensor:
+    return LowerBoundFn.apply(x, torch.tensor([bound], dtype=x.dtype))
+
+
+def nonneg_reparam(p: torch.Tensor, minimum: float) -> torch.Tensor:
+    return lower_bound(p, (minimum + O.PEDESTAL) ** 0.5) ** 2 - O.PEDESTAL
+
+
+def gdn(x: torch.Tensor, beta: torch.Tensor, gamma: torch.Tensor, inverse: bool, beta_min: float = 1e-6) -> torch.Tensor:
+    C = x.shape[1]
+    b = nonneg_reparam(beta, beta_min)
+    g = nonneg_reparam(gamma, 0.0).reshape(C, C, 1, 1)
+    norm = F.conv2d(x ** 2, g, b)
+    return x * (torch.sqrt(norm) if inverse else torch.rsqrt(norm))
+
+
+class _Round(torch.autograd.Function):
+    """value rounded to bf16, gradient passed through"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _GradRound(torch.autograd.Function):
+    """identity whose incoming gradient is rounded to bf16"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _r(x, bf16):
+    return _Round.apply(x) if bf16 else x
+
+
+def _g(x, bf16):
+    return _GradRound.apply(x) if bf16 else x
+
+
+def analysis(x: torch.Tensor, layers: Sequence[dict], bf16: bool = True) -> torch.Tensor:
+    """layers[i] = {'weight', 'bias'?, 'beta'?, 'gamma'?} (stored parameters, leaf tensors with requires_grad)"""
+    fx = x
+    for L in layers:
+        fx = _g(O.reflect_conv_s2(_r(fx, bf16), _r(L['weight'], bf16), L.get('bias')), bf16)
+        if L.get('beta') is not None:
+            fx = gdn(fx, L['beta'], L['gamma'], False)
+    return fx
+
+
+def synthesis(y: torch.Tensor, layers: Sequence[dict], bf16: bool = True) -> torch.Tensor:
+    fx = y
+    for L in layers:
+        fx = _g(O.deconv_s2(_r(fx, bf16), _r(L['weight'], bf16), L.get('bias')), bf16)
+        if L.get('beta') is not None:
+            fx = gdn(fx, L['beta'], L['gamma'], True)
+    return fx
+
+
+def entropy_forward(params: dict, y: torch.Tensor, noise: Optional[torch.Tensor], n_filters: int, form: str = 'plain',
+                    bound: float = 1e-9):
+    """EntropyBottleneck.forward in train mode: y + noise, likelihood with the LowerBound rule.  noise: like y."""
+    perm = list(range(y.dim()))
+    perm[0], perm[1] = 1, 0
+    v = y.permute(*perm).contiguous()
+    shape = v.shape
+    v = v.reshape(shape[0], 1, -1)
+    if noise is not None:
+        v = v + noise.permute(*perm).reshape(shape[0], 1, -1)
+
+    def logits(t):
+        for i in range(n_filters + 1):
+            t = torch.matmul(F.softplus(params[f'_matrix{i}']), t) + params[f'_bias{i}']
+            if i < n_filters:
+                t = t + torch.tanh(params[f'_factor{i}']) * torch.tanh(t)
+        return t
+    lower, upper = logits(v - 0.5), logits(v + 0.5)
+    if form == 'plain':
+        lik = torch.sigmoid(upper) - torch.sigmoid(lower)
+    else:
+        s = -torch.sign(lower + upper).detach()
+        lik = torch.abs(torch.sigmoid(s * upper) - torch.sigmoid(s * lower))
+    lik = lower_bound(lik, bound)
+    return v.reshape(shape).permute(*perm).contiguous(), lik.reshape(shape).permute(*perm).contiguous()
+
+
+def aux_loss(params: dict, n_filters: int, target: torch.Tensor) -> torch.Tensor:
+    """EntropyBottleneck.loss(): |logits(quantiles) - target| summed, gradient to `quantiles` only"""
+    t = params['quantiles']
+    for i in range(n_filters + 1):
+        t = torch.matmul(F.softplus(params[f'_matrix{i}'].detach()), t) + params[f'_bias{i}'].detach()
+        if i < n_filters:
+            t = t + torch.tanh(params[f'_factor{i}'].detach()) * torch.tanh(t)
+    return torch.abs(t - target).sum()
+
+
+def rd_loss(x: torch.Tensor, x_r: torch.Tensor, p_y: torch.Tensor, distortion_lambda: float):
+    """GeneralLoss: rate = -sum log2 p / (B H W), dist = 255^2 MSE; loss = rate + lambda dist"""
+    rate = -torch.sum(torch.log2(p_y)) / (x.size(0) * x.size(2) * x.size(3))
+    dist = 255 ** 2 * F.mse_loss(x_r, x)
+    return rate + distortion_lambda * dist, rate, dist

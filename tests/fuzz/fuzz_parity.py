@@ -68,9 +68,9 @@ for case in range(n_cases):
             fails += 1
             print('ERROR', case, prec, kw, (n, h, w), repr(e)[:200])
             continue
-    if not (torch.isfinite(y_ref).all() and torch.isfinite(xr_ref).all() and float(xr_ref.abs().max()) < 1e6):
+    if not (torch.isfinite(y_ref).all() and torch.isfinite(xr_ref).all()):
         skipped += 1  # an untrained residual / IGDN stack can overflow fp32 in the reference itself
-        continue
+        continue  # (large finite magnitudes are NOT skipped: the f16x3 range guard repeats such calls on fp32)
     ey = float((y - y_ref).abs().max() / max(1.0, float(y_ref.abs().max())))
     ex = float((x_r[0].cpu() - xr_ref).abs().max() / max(1.0, float(xr_ref.abs().max())))
     assert all((t is None) != kw['multiscale_analysis'] for t in x_r[1:])  # colour layers only with multiscale_analysis

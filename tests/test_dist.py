@@ -131,3 +131,35 @@ def test_two_ranks_write_the_cae_store_of_one_rank(tmp_path):
     for f in files:
         assert open(os.path.join(one, '0', '0', f), 'rb').read() == open(os.path.join(two, '0', '0', f), 'rb').read(), f
     assert np.array_equal(zarrio.decompress_image(one), zarrio.decompress_image(two))
+
+
+def _grad_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from cnn_autoencoder_amd import train
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)  # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(7, 300), torch.nn.Linear(300, 5))
+    for p in net.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))
+    net[1].bias.grad = None  # a parameter that received no gradient on this rank
+    reducer = train.GradReducer(net.parameters(), bucket_bytes=4096)  # several buckets
+    reducer.reduce()
+    torch.save([p.grad.clone() for p in net.parameters()], os.path.join(out_dir, f'g{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_average_their_gradients(tmp_path):
+    """train.GradReducer (data-parallel gradient all-reduce replacing nn.DataParallel, _autoencoders.py:517): every
+    rank ends with the mean gradient, over several buckets, missing gradients counted as zero."""
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = [torch.load(str(tmp_path / f'g{r}.pt'), weights_only=False) for r in range(world)]
+    for a, b in zip(*g):
+        assert torch.equal(a, b)
+    assert torch.allclose(g[0][0], torch.full_like(g[0][0], 1.5))
+    assert torch.allclose(g[0][3], torch.zeros_like(g[0][3]))

@@ -1,0 +1,282 @@
+"""Training path (BASELINE config 5) on the GPU: the bf16 convolution kernels, their data and weight
+gradients, the fp32 GDN gradient, whole-track gradients and a 20-step loss curve against the CPU restatement
+(oracle/train_oracle.py: torch-CPU autograd of the reference-pinned conv stacks + compressai's gradient rules).
+
+Tolerances (stated per north_star: bf16 convolutions, fp32 GDN):
+  * against the restatement with the SAME bf16 rounding points: 1e-3 of the tensor's largest magnitude (only the
+    summation order differs; observed ~1e-5);
+  * fp32 GDN forward / backward alone: 1e-4;
+  * against the plain fp32 restatement: 3e-2 (what bf16 operands cost), reported so that the cost stays visible.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def cae(built_lib):
+    import cnn_autoencoder_amd as cae
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    return cae
+
+
+def rel(got: torch.Tensor, want: torch.Tensor) -> float:
+    return float((got.double().cpu() - want.double().cpu()).abs().max() / max(float(want.abs().max()), 1e-30))
+
+
+def bf(x):
+    return x.bfloat16().float()
+
+
+def to_t(x, cp, dtype):
+    """NCHW cpu -> T layout on the GPU"""
+    n, c, h, w = x.shape
+    t = torch.zeros((n, h, w, cp), dtype=torch.float32)
+    t[..., :c] = x.permute(0, 2, 3, 1)
+    return t.to(dtype).cuda()
+
+
+def from_t(t, c):
+    return t[..., :c].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize('cin,cout,ks,shape', [(3, 128, 3, (2, 40, 56)), (128, 128, 3, (2, 37, 45)), (48, 192, 5, (1, 33, 50)),
+                                               (160, 64, 5, (1, 18, 21)), (32, 32, 3, (3, 16, 16))])
+def test_conv_kernels(cae, cin, cout, ks, shape):
+    """conv forward, its data gradient (extended domain + fold) and weight gradient against F.conv2d autograd on the
+    same bf16-rounded operands."""
+    from cnn_autoencoder_amd import _lib, train
+    L = _lib.lib()
+    torch.manual_seed(cin + cout)
+    n, h, w = shape
+    x = bf(torch.randn(n, cin, h, w)).requires_grad_(True)
+    wt = bf(torch.randn(cout, cin, ks, ks) / (cin * ks * ks) ** 0.5).requires_grad_(True)
+    b = torch.randn(cout)
+    P = ks // 2
+    z = F.conv2d(F.pad(x, (P, P, P, P), mode='reflect'), wt, b, stride=2)
+    gz = bf(torch.randn_like(z))
+    z.backward(gz)
+    cip, cop = train._pad32(cin), train._pad32(cout)
+    oh, ow = z.shape[2:]
+    x16 = to_t(x.detach(), cip, torch.bfloat16)
+    wp = train._pack(wt.detach().cuda(), 1, ks)
+    bias_p = torch.zeros(cop).cuda()
+    bias_p[:cout] = b.cuda()
+    z32 = torch.empty((n, oh, ow, cop), device='cuda')
+    z16 = torch.empty((n, oh, ow, cop), device='cuda', dtype=torch.bfloat16)
+    _lib.check(L.cae_t_conv_forward(x16.data_ptr(), n, h, w, cip, wp.data_ptr(), ks, z32.data_ptr(), z16.data_ptr(), cop,
+                                    bias_p.data_ptr(), None))
+    assert rel(from_t(z32, cout), z.detach()) < 1e-3
+    assert float(z32[..., cout:].abs().max()) == 0.0 if cop > cout else True
+    assert rel(from_t(z16, cout), z.detach()) < 1e-2  # (bf16 copy of the output)
+    # data gradient
+    g16 = to_t(gz, cop, torch.bfloat16)
+    wpd = train._pack(wt.detach().cuda(), 0, ks)
+    gext = torch.full((n, h + 2 * P, w + 2 * P, cip), float('nan'), device='cuda')
+    _lib.check(L.cae_t_conv_dgrad_ext(g16.data_ptr(), n, oh, ow, cop, wpd.data_ptr(), ks, h, w, gext.data_ptr(), cip, None))
+    gx16 = torch.empty((n, h, w, cip), device='cuda', dtype=torch.bfloat16)
+    _lib.check(L.cae_t_fold_to_bf16(gext.data_ptr(), n, h, w, P, cip, gx16.data_ptr(), None))
+    assert rel(from_t(gx16, cin), x.grad) < 1e-2  # (stored as bf16)
+    # weight gradient
+    gw = torch.empty((ks * ks, cip, cop), device='cuda')
+    _lib.check(L.cae_t_wgrad(x16.data_ptr(), n, h, w, cip, g16.data_ptr(), oh, ow, cop, ks, 1, gw.data_ptr(), None))
+    assert rel(train._weight_grad(gw, (cout, cin), ks), wt.grad) < 1e-3
+    gb = torch.empty(cop, device='cuda')
+    _lib.check(L.cae_t_colsum(g16.data_ptr(), n * oh * ow, cop, gb.data_ptr(), None))
+    assert rel(gb[:cout], gz.sum(dim=(0, 2, 3))) < 1e-3
+
+
+@pytest.mark.parametrize('cin,cout,ks,shape', [(192, 128, 3, (2, 9, 13)), (128, 128, 3, (1, 20, 17)), (128, 3, 3, (2, 24, 24)),
+                                               (48, 96, 5, (1, 11, 19)), (32, 32, 5, (2, 16, 16))])
+def test_deconv_kernels(cae, cin, cout, ks, shape):
+    from cnn_autoencoder_amd import _lib, train
+    L = _lib.lib()
+    torch.manual_seed(cin * 3 + cout)
+    n, h, w = shape
+    x = bf(torch.randn(n, cin, h, w)).requires_grad_(True)
+    wt = bf(torch.randn(cin, cout, ks, ks) / (cin * ks * ks / 4) ** 0.5).requires_grad_(True)
+    b = torch.randn(cout)
+    z = F.conv_transpose2d(x, wt, b, stride=2, padding=ks // 2, output_padding=1)
+    gz = bf(torch.randn_like(z))
+    z.backward(gz)
+    cip, cop = train._pad32(cin), train._pad32(cout)
+    x16 = to_t(x.detach(), cip, torch.bfloat16)
+    wp = train._pack(wt.detach().cuda(), 0, ks)
+    bias_p = torch.zeros(cop).cuda()
+    bias_p[:cout] = b.cuda()
+    z32 = torch.full((n, 2 * h, 2 * w, cop), float('nan'), device='cuda')
+    _lib.check(L.cae_t_deconv_forward(x16.data_ptr(), n, h, w, cip, wp.data_ptr(), ks, z32.data_ptr(), None, cop,
+                                      bias_p.data_ptr(), None))
+    assert rel(from_t(z32, cout), z.detach()) < 1e-3
+    g16 = to_t(gz, cop, torch.bfloat16)
+    wpd = train._pack(wt.detach().cuda(), 1, ks)
+    gx32 = torch.empty((n, h, w, cip), device='cuda')
+    _lib.check(L.cae_t_deconv_dgrad(g16.data_ptr(), n, h, w, cop, wpd.data_ptr(), ks, gx32.data_ptr(), None, cip, None))
+    assert rel(from_t(gx32, cin), x.grad) < 1e-3
+    gw = torch.empty((ks * ks, cop, cip), device='cuda')
+    _lib.check(L.cae_t_wgrad(g16.data_ptr(), n, 2 * h, 2 * w, cop, x16.data_ptr(), h, w, cip, ks, 0, gw.data_ptr(), None))
+    assert rel(train._weight_grad(gw, (cin, cout), ks), wt.grad) < 1e-3
+
+
+@pytest.mark.parametrize('inverse', [False, True])
+@pytest.mark.parametrize('c,shape,pad', [(128, (2, 19, 23), 1), (48, (1, 40, 31), 2), (192, (1, 9, 14), 0), (32, (3, 8, 8), 1)])
+def test_gdn_kernels(cae, inverse, c, shape, pad):
+    """fp32 GDN / IGDN forward and backward (with the reflect fold of an extended-domain gradient) against autograd."""
+    from cnn_autoencoder_amd import _lib, train
+    L = _lib.lib()
+    torch.manual_seed(c + pad)
+    n, h, w = shape
+    cp = train._pad32(c)
+    z = torch.randn(n, c, h, w).requires_grad_(True)
+    beta = (torch.rand(c) + 0.5).requires_grad_(True)
+    gamma = (0.1 * torch.eye(c) + 0.02 * torch.rand(c, c)).requires_grad_(True)
+    norm = F.conv2d(z ** 2, gamma.reshape(c, c, 1, 1), beta)
+    y = z * (torch.sqrt(norm) if inverse else torch.rsqrt(norm))
+    gext = torch.randn(n, c, h + 2 * pad, w + 2 * pad)
+    # fold: gradient of reflect padding (pad > 0) = what F.pad's backward does
+    yp = F.pad(y, (pad,) * 4, mode='reflect') if pad else y
+    yp.backward(gext)
+    beta_p = torch.ones(cp)
+    beta_p[:c] = beta.detach()
+    gamma_p = torch.zeros(cp, cp)
+    gamma_p[:c, :c] = gamma.detach()
+    z32 = to_t(z.detach(), cp, torch.float32)
+    y32 = torch.empty_like(z32)
+    y16 = torch.empty_like(z32, dtype=torch.bfloat16)
+    beta_d, gamma_d = beta_p.cuda(), gamma_p.cuda()  # (kept alive: the call takes raw pointers)
+    _lib.check(L.cae_t_gdn_forward(z32.data_ptr(), n * h * w, cp, beta_d.data_ptr(), gamma_d.data_ptr(),
+                                   int(inverse), y32.data_ptr(), y16.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert rel(from_t(y32, c), y.detach()) < 1e-4
+    assert rel(from_t(y16, c), y.detach()) < 1e-2
+    ge = to_t(gext, cp, torch.float32)
+    gz16, gb, gg = train._gdn_backward(z32, ge, pad, beta_d, gamma_d, inverse)
+    assert rel(from_t(gz16, c), z.grad) < 1e-2  # (stored as bf16)
+    assert rel(gb[:c], beta.grad) < 1e-4
+    assert rel(gg[:c, :c], gamma.grad) < 1e-4
+
+
+def _models(cae, cfg, seed):
+    """product model (train mode) + oracle parameter lists sharing the same values"""
+    from cnn_autoencoder_amd import synth
+    from conftest import oracle_layers
+    state = synth.synthetic_state(cfg, seed=seed)
+    model = cae.autoencoder_from_state_dict(state, train=True)
+    leaf = lambda t: None if t is None else t.detach().clone().requires_grad_(True)  # noqa: E731
+    layers = {part: [{k: leaf(v) for k, v in l.items() if k in ('weight', 'bias', 'beta', 'gamma')}
+                     for l in oracle_layers(state, part)] for part in ('encoder', 'decoder')}
+    return state, model, layers
+
+
+def _named_grads(module, track):
+    out = {}
+    for name, p in module.named_parameters():
+        if p.grad is not None:
+            out[name] = p.grad.detach().cpu()
+    return out
+
+
+@pytest.mark.parametrize('cfgkw,shape', [(dict(channels_net=32, channels_bn=48, compression_level=3), (2, 40, 56)),
+                                         (dict(channels_net=128, channels_bn=192, compression_level=4), (1, 64, 64)),
+                                         (dict(channels_net=32, channels_bn=48, compression_level=2, act_layer_type=None, bias=True,
+                                               kernel_size=5), (2, 37, 45))])
+def test_track_gradients_match_the_restatement(cae, cfgkw, shape):
+    from cnn_autoencoder_amd import synth
+    from oracle import train_oracle as T
+    cfg = dict(synth.CANONICAL, **cfgkw)
+    state, model, layers = _models(cae, cfg, seed=21)
+    enc, dec = model['encoder'].module, model['decoder'].module
+    n, h, w = shape
+    torch.manual_seed(1)
+    x = torch.rand(n, 3, h, w)
+    # analysis
+    y = enc(x.cuda())
+    gy = torch.randn_like(y.detach()).cpu()
+    y.backward(gy.cuda())
+    y_ref = T.analysis(x, layers['encoder'], bf16=True)
+    y_ref.backward(gy)
+    assert y.shape == y_ref.shape and rel(y.detach(), y_ref.detach()) < 1e-3
+    y32 = T.analysis(x, [{k: (v.detach() if v is not None else None) for k, v in l.items()} for l in layers['encoder']], bf16=False)
+    assert rel(y.detach(), y32) < 3e-2
+    got = _named_grads(enc, 'analysis_track')
+    assert got, 'no gradients reached the encoder parameters'
+    for i, l in enumerate(layers['encoder']):
+        for key, sub in (('weight', 'model.0.weight'), ('bias', 'model.0.bias'), ('beta', 'model.1.beta'), ('gamma', 'model.1.gamma')):
+            if l.get(key) is not None:
+                name = f'analysis_track.{i}.{sub}'
+                assert rel(got[name], l[key].grad) < 1e-3, name
+    # synthesis (from latents of realistic magnitude; h, w even multiples are not required)
+    lh, lw = y.shape[2:]
+    yq = torch.round(y_ref.detach()).requires_grad_(True)
+    yq_dev = yq.detach().cuda().requires_grad_(True)
+    x_r, _ = dec(yq_dev)
+    gx = torch.randn_like(x_r[0].detach()).cpu()
+    x_r[0].backward(gx.cuda())
+    xr_ref = T.synthesis(yq, layers['decoder'], bf16=True)
+    xr_ref.backward(gx)
+    scale = max(1.0, float(xr_ref.abs().max()))
+    assert float((x_r[0].detach().cpu() - xr_ref.detach()).abs().max()) / scale < 1e-3
+    assert rel(yq_dev.grad, yq.grad) < 1e-3
+    got = _named_grads(dec, 'synthesis_track')
+    for i, l in enumerate(layers['decoder']):
+        for key, sub in (('weight', 'model.0.weight'), ('bias', 'model.0.bias'), ('beta', 'model.1.beta'), ('gamma', 'model.1.gamma')):
+            if l.get(key) is not None:
+                name = f'synthesis_track.{i}.{sub}'
+                assert rel(got[name], l[key].grad) < 1e-3, name
+
+
+def test_twenty_training_steps_follow_the_restatement(cae):
+    """train.train_step (forward_func -> GeneralLoss -> backward -> aux backward -> clip 1.0 -> per-module Adam, the
+    quantiles in the `_aux` optimiser) against the same loop on the CPU restatement, same noise: the loss curve matches
+    step for step."""
+    from cnn_autoencoder_amd import criteria, synth, train
+    from oracle import train_oracle as T
+    cfg = dict(synth.CANONICAL, channels_net=32, channels_bn=48, compression_level=3)
+    state, model, layers = _models(cae, cfg, seed=22)
+    eb = model['fact_ent'].module
+    n_filters = len(eb.filters)
+    eb_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in eb.named_parameters()}
+    target = eb.target.detach().cpu()
+    lam = 0.01
+    criterion = criteria.GeneralLoss(distortion_lambda=lam)
+    opts = train.setup_optim(model, learning_rate=1e-3, aux_learning_rate=1e-2)
+    assert set(opts) == {'encoder', 'decoder', 'fact_ent', 'fact_ent_aux'}
+    flat = lambda ls: [t for l in ls for t in l.values() if t is not None]  # noqa: E731
+    ref_groups = dict(encoder=flat(layers['encoder']), decoder=flat(layers['decoder']),
+                      fact_ent=[v for k, v in eb_ref.items() if 'quantiles' not in k],
+                      fact_ent_aux=[eb_ref['quantiles']])
+    ref_opts = {k: torch.optim.Adam([dict(params=v, lr=1e-2 if k.endswith('_aux') else 1e-3)]) for k, v in ref_groups.items()}
+    gen = torch.Generator().manual_seed(3)
+    losses, ref_losses = [], []
+    for step in range(20):
+        x = torch.rand(4, 3, 48, 64, generator=gen)
+        noise = torch.rand(4, 48, 6, 8, generator=gen) - 0.5
+        eb.fixed_noise = noise
+        ld = train.train_step(x.cuda(), model, criterion, opts)
+        losses.append(float(ld['loss']))
+        # restatement
+        y = T.analysis(x, layers['encoder'])
+        y_q, p_y = T.entropy_forward(eb_ref, y, noise, n_filters, form=eb.likelihood_form)
+        x_r = T.synthesis(y_q, layers['decoder'])
+        loss, rate, dist = T.rd_loss(x, x_r, p_y, lam)
+        loss.backward()
+        T.aux_loss(eb_ref, n_filters, target).backward()
+        for opt in ref_opts.values():
+            torch.nn.utils.clip_grad_norm_(opt.param_groups[0]['params'], max_norm=1.0)
+            opt.step()
+            opt.zero_grad()
+        ref_losses.append(float(loss))
+        assert float(ld['rate_loss']) == pytest.approx(float(rate), rel=2e-3), step
+        assert float(ld['dist'][0]) == pytest.approx(float(dist), rel=2e-3), step
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-3)
+    assert losses[-1] < losses[0]  # and it trains
+    # parameters after 20 steps
+    w_ref = layers['encoder'][0]['weight'].detach()
+    w_got = model['encoder'].module.analysis_track[0].model[0].weight.detach().cpu()
+    assert rel(w_got, w_ref) < 1e-2
+    assert rel(eb.quantiles.detach().cpu(), eb_ref['quantiles'].detach()) < 1e-3
