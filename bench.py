@@ -162,6 +162,17 @@ def kernel_table(cfg, H, B, enc_ms, enc_calls, dec_ms, dec_calls, precision):
     return out, stack, peak
 
 
+HOST_USE = {}  # host CPU use of the last timed run: average busy CPUs of this process, cgroup throttling
+
+
+def _throttled():
+    try:
+        kv = dict(l.split() for l in open('/sys/fs/cgroup/cpu.stat'))
+        return int(kv['nr_throttled']), int(kv['throttled_usec'])
+    except Exception:
+        return None
+
+
 def timed_run(coder, batches, steps, world, dist, cdev):
     """K steps, software-pipelined, bracketed by barrier + synchronise; max over ranks.  -> (seconds, gathered stats)"""
     from cnn_autoencoder_amd import slide
@@ -174,12 +185,17 @@ def timed_run(coder, batches, steps, world, dist, cdev):
 
     seq = [batches[k % len(batches)] for k in range(steps)]
     fence()
+    cpu0, thr0 = time.process_time(), _throttled()
     t0 = time.perf_counter()
     local_stats, _ = coder.run(seq)
     local_stats = local_stats.to(cdev)
     all_stats = slide.gather_stats(local_stats)  # the one collective of the path (RCCL all_gather)
     fence()
     dt = time.perf_counter() - t0
+    thr1 = _throttled()
+    HOST_USE.update(cpus_busy=(time.process_time() - cpu0) / dt,
+                    cgroup_throttled_periods=None if thr0 is None else thr1[0] - thr0[0],
+                    cgroup_throttled_ms=None if thr0 is None else (thr1[1] - thr0[1]) / 1e3)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -318,7 +334,9 @@ def main():
         gpu_ms = (sum(prof[0]) / max(prof[1], 1), sum(prof[2]) / max(prof[3], 1))
         f16 = args.precision == 'f16x3'
         from cnn_autoencoder_amd import _lib
-        threads = int(_lib.lib().cae_coder_threads(coder.coder_threads, B))
+        threads = dict(encode=int(_lib.lib().cae_coder_threads(coder.encode_threads, (B + 1) // 2)),
+                       decode=int(_lib.lib().cae_coder_threads(coder.decode_threads, (B + 1) // 2)),
+                       cpu_budget=int(_lib.lib().cae_cpu_budget()))
         line = {
             'metric': 'tiles/sec, compress+decompress round trip of 1024x1024x3 histology tiles',
             'value': total_tiles / dt,
@@ -352,11 +370,13 @@ def main():
             'gpu_ms_per_step': {'analysis': gpu_ms[0], 'synthesis': gpu_ms[1]},
             'host_ms_per_step': {k: 1e3 * v / args.steps for k, v in coder.timers.items()},
             'host_coder_threads': threads,
+            'host_use': dict(HOST_USE),
             'fp32_fallbacks': coder.enc.fp32_fallbacks + coder.dec.fp32_fallbacks,
         }
         if threads:
-            line['host_cpu_ms_per_step'] = {k: 1e3 * v / args.steps * threads for k, v in coder.timers.items()
-                                            if k in ('host_encode', 'host_decode')}
+            # wall time of a pool x its threads: an upper bound of the CPU time (threads wait for one another's tail)
+            line['host_cpu_ms_per_step'] = {k: 1e3 * coder.timers[k] / args.steps * threads[k.split('_')[1]]
+                                            for k in ('host_encode', 'host_decode')}
         line['cpu_baseline'] = None
         if world == 1 and not args.no_cpu_baseline:
             report, per_tile, cpu_payloads, cpu_recs = cpu_baseline(state, cfg, list(tiles_host[:16]))

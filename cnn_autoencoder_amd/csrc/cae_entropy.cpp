@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -30,6 +31,10 @@ static constexpr uint64_t kRansL = 1ull << 31;
 static constexpr uint32_t kPrecision = 16;
 static constexpr uint32_t kBypassBits = 4;
 static constexpr uint32_t kMaxBypass = (1u << kBypassBits) - 1;
+#ifndef CAE_CODER_LOCKSTEP
+#define CAE_CODER_LOCKSTEP 2
+#endif
+static constexpr int kLock = CAE_CODER_LOCKSTEP;  // streams one thread codes in lockstep
 
 static inline uint64_t mul_hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 
@@ -202,25 +207,22 @@ int encode_streams(const EntropyTables &T, const int32_t *const *symbols, int hw
             const uint64_t q = mul_hi(xx, e.rcp_freq) >> e.rcp_shift;
             xs = xx + e.bias + q * e.cmpl_freq;
         };
-        if constexpr (NS == 2) {
-            uint64_t x0 = x[0], x1 = x[1];
-            uint32_t *p0 = w[0].ptr, *p1 = w[1].ptr;
-            const int32_t *s0 = s[0], *s1 = s[1];
-            for (int i = hw - 1; i >= 0; --i) {
-                step(x0, p0, s0[i]);
-                step(x1, p1, s1[i]);
+        {
+            // NS independent dependency chains per loop iteration (locals, so they stay in registers)
+            uint64_t xl[NS];
+            uint32_t *pl[NS];
+            for (int k = 0; k < NS; ++k) {
+                xl[k] = x[k];
+                pl[k] = w[k].ptr;
             }
-            x[0] = x0;
-            x[1] = x1;
-            w[0].ptr = p0;
-            w[1].ptr = p1;
-        } else {
-            uint64_t x0 = x[0];
-            uint32_t *p0 = w[0].ptr;
-            const int32_t *s0 = s[0];
-            for (int i = hw - 1; i >= 0; --i) step(x0, p0, s0[i]);
-            x[0] = x0;
-            w[0].ptr = p0;
+            for (int i = hw - 1; i >= 0; --i) {
+#pragma GCC unroll 8
+                for (int k = 0; k < NS; ++k) step(xl[k], pl[k], s[k][i]);
+            }
+            for (int k = 0; k < NS; ++k) {
+                x[k] = xl[k];
+                w[k].ptr = pl[k];
+            }
         }
     }
     int rc = CAE_OK;
@@ -321,25 +323,49 @@ int decode_streams(const EntropyTables &T, const uint8_t *const *bufs, const siz
     return CAE_OK;
 }
 
-// Default size of the coder pool: CAE_CODER_THREADS, else the CPUs this process may run on (divided among the
-// ranks of the node), capped at 16
-// (one rank per GPU shares the host with the other ranks, and a container's CPU share is usually far below the
-// host's thread count; oversubscribing a 16-CPU share with 256 threads made small-tile batches 4x slower).
+// CPUs this process may keep busy: its affinity mask, capped by the cgroup CPU quota (a container's `cpu.max`; running
+// more threads than the quota allows gets the WHOLE process throttled for the rest of each scheduler period -- on the
+// 16-CPU share of a one-GPU box 2 x 16 coder threads stalled the thread that feeds the GPU), divided among the ranks
+// of the node (torch.distributed.run exports LOCAL_WORLD_SIZE).
+int cpu_budget() {
+    static const int cached = [] {
+        int ncpu = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) ncpu = std::min(ncpu > 0 ? ncpu : 1 << 20, CPU_COUNT(&set));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+            char q[64] = {0};
+            long period = 0;
+            if (fscanf(f, "%63s %ld", q, &period) == 2 && period > 0 && strcmp(q, "max") != 0) {
+                const long quota = atol(q);
+                if (quota > 0) ncpu = std::min<long>(ncpu, std::max<long>(1, (quota + period - 1) / period));
+            }
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+            long quota = -1, period = 100000;
+            if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(h, "%ld", &period) != 1) period = 100000;
+                fclose(h);
+            }
+            if (quota > 0 && period > 0) ncpu = std::min<long>(ncpu, std::max<long>(1, (quota + period - 1) / period));
+        }
+        int local_world = 1;
+        if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, std::atoi(e));
+        return std::max(1, ncpu / local_world);
+    }();
+    return cached;
+}
+
+// Default size of one coder pool: CAE_CODER_THREADS, else the CPU budget, capped at 16.  (The pipelined drivers, which
+// run an encode and a decode pool side by side, split the budget themselves: slide.SlideCoder.)
 int default_threads() {
     static const int cached = [] {
         if (const char *e = std::getenv("CAE_CODER_THREADS")) {
             const int v = std::atoi(e);
             if (v > 0) return v;
         }
-        int ncpu = (int)std::thread::hardware_concurrency();
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof(set), &set) == 0) ncpu = std::min(ncpu > 0 ? ncpu : 1 << 20, CPU_COUNT(&set));
-        // one rank per GPU (torch.distributed.run exports LOCAL_WORLD_SIZE): the ranks of a node share its cores,
-        // and every rank runs an encode and a decode pool side by side
-        int local_world = 1;
-        if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, std::atoi(e));
-        if (local_world > 1) ncpu = std::max(4, ncpu / (2 * local_world));
-        return std::max(1, std::min(ncpu, 16));
+        return std::max(1, std::min(cpu_budget(), 16));
     }();
     return cached;
 }
@@ -427,6 +453,8 @@ int cae_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *c
     return CAE_OK;
 }
 
+int cae_cpu_budget(void) { return cpu_budget(); }
+
 int cae_coder_threads(int requested, int n_streams) {
     int t = requested > 0 ? requested : default_threads();
     if (n_streams > 0) t = std::min(t, n_streams);
@@ -445,16 +473,27 @@ int cae_rans_encode_batch(cae_model_t *mm, const int32_t *symbols, int n_streams
     }
     const EntropyTables &T = m->ent;
     const size_t per = (size_t)T.channels * hw;
-    // work item = two streams coded in lockstep (a lone last stream goes alone)
-    const int items = (n_streams + 1) / 2;
+    // work item = kLock streams coded in lockstep (the remainder in smaller groups)
+    const int items = (n_streams + kLock - 1) / kLock;
     int rc = parallel_streams(items, threads, [&](int it) {
-        const int i = 2 * it;
-        if (i + 1 < n_streams) {
-            const int32_t *sy[2] = {symbols + per * i, symbols + per * (i + 1)};
-            return encode_streams<2>(T, sy, hw, &out_bufs[i], &out_lens[i]);
+        int i = kLock * it;
+        const int end = std::min(n_streams, i + kLock);
+        int r = CAE_OK;
+        const int32_t *sy[kLock];
+        if (end - i == kLock) {
+            for (int k = 0; k < kLock; ++k) sy[k] = symbols + per * (i + k);
+            return encode_streams<kLock>(T, sy, hw, &out_bufs[i], &out_lens[i]);
         }
-        const int32_t *sy[1] = {symbols + per * i};
-        return encode_streams<1>(T, sy, hw, &out_bufs[i], &out_lens[i]);
+        for (; r == CAE_OK && i + 1 < end; i += 2) {
+            sy[0] = symbols + per * i;
+            sy[1] = symbols + per * (i + 1);
+            r = encode_streams<2>(T, sy, hw, &out_bufs[i], &out_lens[i]);
+        }
+        if (r == CAE_OK && i < end) {
+            sy[0] = symbols + per * i;
+            r = encode_streams<1>(T, sy, hw, &out_bufs[i], &out_lens[i]);
+        }
+        return r;
     });
     if (rc != 0)
         for (int i = 0; i < n_streams; ++i) {
@@ -462,6 +501,32 @@ int cae_rans_encode_batch(cae_model_t *mm, const int32_t *symbols, int n_streams
             out_bufs[i] = nullptr;
         }
     return rc;
+}
+
+int cae_rans_encode_packed(cae_model_t *mm, const int32_t *symbols, int n_streams, int hw, uint8_t **out_buf,
+                           size_t *offsets, int threads) {
+    if (!out_buf || !offsets) return fail(CAE_ERR_ARG, "NULL argument");
+    *out_buf = nullptr;
+    std::vector<uint8_t *> bufs((size_t)std::max(n_streams, 1), nullptr);
+    std::vector<size_t> lens((size_t)std::max(n_streams, 1), 0);
+    int rc = cae_rans_encode_batch(mm, symbols, n_streams, hw, bufs.data(), lens.data(), threads);
+    if (rc) return rc;
+    offsets[0] = 0;
+    for (int i = 0; i < n_streams; ++i) offsets[i + 1] = offsets[i] + lens[i];
+    uint8_t *packed = (uint8_t *)malloc(offsets[n_streams] ? offsets[n_streams] : 1);
+    if (!packed) rc = fail(CAE_ERR_NOMEM, "out of memory (%zu bytes)", offsets[n_streams]);
+    if (rc == CAE_OK)
+        rc = parallel_streams(n_streams, threads, [&](int i) {
+            memcpy(packed + offsets[i], bufs[i], lens[i]);
+            return (int)CAE_OK;
+        });
+    for (int i = 0; i < n_streams; ++i) free(bufs[i]);
+    if (rc) {
+        free(packed);
+        return rc;
+    }
+    *out_buf = packed;
+    return CAE_OK;
 }
 
 int cae_rans_decode_batch(cae_model_t *mm, const uint8_t *const *bufs, const size_t *lens, int n_streams, int hw,
@@ -472,15 +537,26 @@ int cae_rans_decode_batch(cae_model_t *mm, const uint8_t *const *bufs, const siz
     if (n_streams < 1 || hw < 0) return fail(CAE_ERR_ARG, "bad shape");
     const EntropyTables &T = m->ent;
     const size_t per = (size_t)T.channels * hw;
-    const int items = (n_streams + 1) / 2;
+    const int items = (n_streams + kLock - 1) / kLock;
     return parallel_streams(items, threads, [&](int it) {
-        const int i = 2 * it;
-        if (i + 1 < n_streams) {
-            int32_t *sy[2] = {symbols + per * i, symbols + per * (i + 1)};
-            return decode_streams<2>(T, bufs + i, lens + i, hw, sy);
+        int i = kLock * it;
+        const int end = std::min(n_streams, i + kLock);
+        int r = CAE_OK;
+        int32_t *sy[kLock];
+        if (end - i == kLock) {
+            for (int k = 0; k < kLock; ++k) sy[k] = symbols + per * (i + k);
+            return decode_streams<kLock>(T, bufs + i, lens + i, hw, sy);
         }
-        int32_t *sy[1] = {symbols + per * i};
-        return decode_streams<1>(T, bufs + i, lens + i, hw, sy);
+        for (; r == CAE_OK && i + 1 < end; i += 2) {
+            sy[0] = symbols + per * i;
+            sy[1] = symbols + per * (i + 1);
+            r = decode_streams<2>(T, bufs + i, lens + i, hw, sy);
+        }
+        if (r == CAE_OK && i < end) {
+            sy[0] = symbols + per * i;
+            r = decode_streams<1>(T, bufs + i, lens + i, hw, sy);
+        }
+        return r;
     });
 }
 

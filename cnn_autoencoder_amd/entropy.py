@@ -44,6 +44,49 @@ class LowerBound(nn.Module):
         return _LowerBoundFn.apply(x, self.bound)
 
 
+class PackedStreams:
+    """The rANS streams of one batch in a single library-owned buffer (cae_rans_encode_packed): a read-only sequence of
+    byte strings that is handed from the encoder to the decoder / file writer without per-stream copies.
+    ``len(p)``, ``p.nbytes(i)``, ``p[i]`` (a ``bytes`` copy), iteration, ``==`` with a list of bytes."""
+
+    def __init__(self, ptr: int, offsets):
+        self._ptr = ptr
+        self.offsets = [int(o) for o in offsets]
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def nbytes(self, i: int) -> int:
+        return self.offsets[i + 1] - self.offsets[i]
+
+    def pointer(self, i: int) -> int:
+        return self._ptr + self.offsets[i]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        return ctypes.string_at(self.pointer(i), self.nbytes(i))
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __eq__(self, other):
+        try:
+            return len(other) == len(self) and all(bytes(a) == bytes(b) for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    def __del__(self):
+        if getattr(self, '_ptr', None):
+            try:
+                _lib.lib().cae_free(self._ptr)
+            except Exception:
+                pass
+            self._ptr = None
+
+
 def pmf_to_quantized_cdf(pmf: torch.Tensor, precision: int = 16) -> torch.Tensor:
     """compressai._CXX.pmf_to_quantized_cdf through the C ABI (cae_pmf_to_quantized_cdf)."""
     p = np.ascontiguousarray(pmf.detach().cpu().numpy(), dtype=np.float32)
@@ -361,12 +404,19 @@ class EntropyBottleneck(nn.Module):
                                              _lib.stream_ptr()))
         return out
 
-    def encode_symbols(self, sym_host: np.ndarray, threads: int = 0) -> List[bytes]:
-        """(B,C,hw) int32 host symbols -> one rANS byte string per batch item."""
+    def encode_symbols(self, sym_host: np.ndarray, threads: int = 0, packed: bool = False):
+        """(B,C,hw) int32 host symbols -> one rANS byte string per batch item (``packed``: a PackedStreams, no
+        per-stream copies -- 17 MB of Python-side copying per 32 tiles of 1024^2 otherwise)."""
         h = self._sync_handle()
         sym_host = np.ascontiguousarray(sym_host, dtype=np.int32)
         n = sym_host.shape[0]
         hw = int(np.prod(sym_host.shape[2:])) if sym_host.ndim > 2 else 1
+        if packed:
+            buf = ctypes.c_void_p()
+            offs = (ctypes.c_size_t * (n + 1))()
+            _lib.check(_lib.lib().cae_rans_encode_packed(h.ptr, sym_host.ctypes.data, n, hw, ctypes.byref(buf), offs,
+                                                         threads))
+            return PackedStreams(buf.value, list(offs))
         bufs = (ctypes.c_void_p * n)()
         lens = (ctypes.c_size_t * n)()
         _lib.check(_lib.lib().cae_rans_encode_batch(h.ptr, sym_host.ctypes.data, n, hw, bufs, lens, threads))
@@ -381,9 +431,13 @@ class EntropyBottleneck(nn.Module):
         """rANS byte strings -> (B,C,hw) int32 host symbols (written into `out` when given)."""
         h = self._sync_handle()
         n = len(strings)
-        keep = [bytes(s) for s in strings]
-        bufs = (ctypes.c_char_p * n)(*keep)
-        lens = (ctypes.c_size_t * n)(*[len(s) for s in keep])
+        if isinstance(strings, PackedStreams):  # zero-copy: pointers into the encoder's buffer
+            bufs = (ctypes.c_void_p * n)(*[strings.pointer(i) for i in range(n)])
+            lens = (ctypes.c_size_t * n)(*[strings.nbytes(i) for i in range(n)])
+        else:
+            keep = [s if isinstance(s, bytes) else bytes(s) for s in strings]
+            bufs = (ctypes.c_char_p * n)(*keep)
+            lens = (ctypes.c_size_t * n)(*[len(s) for s in keep])
         if out is None:
             sym = np.empty((n, self.channels, hw), dtype=np.int32)
         else:

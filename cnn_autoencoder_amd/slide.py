@@ -94,12 +94,35 @@ class SlideCoder:
         self.dec = _module(codec._model['decoder'])
         self.eb = _module(codec._model['fact_ent'])
         self.level = len(self.dec.synthesis_track)
-        self.coder_threads = coder_threads
+        self.coder_threads = coder_threads  # the unpipelined compress() / decompress(): one pool at a time
+        # pipelined drivers: an encode pool and a decode pool work side by side (plus this thread, the copy workers and
+        # the HIP runtime's own threads), so the CPU budget (cae_cpu_budget: affinity / cgroup quota / ranks per node) is
+        # SPLIT between them -- decoding costs about twice as much per symbol (2.1 vs 1.1 ns on a Zen 5 core), so it
+        # gets the larger share.  Exceeding a cgroup quota throttles the whole process, GPU feeder included.
+        self.encode_threads, self.decode_threads = self._split_budget(coder_threads)
         self.depth = 3  # batches the analysis runs ahead of the synthesis in run()
         self._pinned = {}
         self._busy = {}  # pinned buffer key -> event of the asynchronous copy that is still reading it
         self._copy_stream = None  # side stream of the H2D copies
         self.timers = {}
+
+    @staticmethod
+    def _split_budget(requested: int = 0):
+        from . import _lib
+        import os
+        if requested and requested > 0:
+            return requested, requested
+        if os.environ.get('CAE_ENC_THREADS', '0') != '0' and os.environ.get('CAE_DEC_THREADS', '0') != '0':
+            return int(os.environ['CAE_ENC_THREADS']), int(os.environ['CAE_DEC_THREADS'])  # (tuning experiments)
+        # Measured on a 16-CPU share (EPYC 9575F, 32 tiles of 1024^2 per batch = 16 lockstep work items per pool,
+        # profiles/r02_experiments.md): decoding costs about twice the CPU time of encoding (2.1 vs 1.1 ns per symbol and
+        # core), so the decode pool gets one thread per work item and the encode pool half as many; 24 runnable
+        # threads on 16 CPUs caused no cgroup throttling (about 11 CPUs busy on average), while pools of 5 + 8 left
+        # the GPU waiting for the host.
+        budget = int(_lib.lib().cae_cpu_budget())
+        dec = max(1, min(16, budget))
+        enc = max(1, min(16, budget // 2))
+        return enc, dec
 
     # ---- simple (unpipelined) entry points ---------------------------------------------------
     @torch.no_grad()
@@ -153,7 +176,7 @@ class SlideCoder:
         pin.numpy()[...] = arr
         with torch.cuda.stream(stream):
             dev = pin.to(_dev(), non_blocking=True)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(blocking=True)
             ev.record(stream)
         self._busy[key] = ev
         return dev, ev
@@ -164,7 +187,7 @@ class SlideCoder:
         stream order; returns the symbols once they are complete."""
         with torch.cuda.device(t.device), torch.cuda.stream(main):
             sym = self.enc.forward_u8_symbols(t, self.eb)  # guarded call: falls back to fp32 by itself
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(blocking=True)
             done.record(main)
         done.synchronize()
         return sym
@@ -173,6 +196,8 @@ class SlideCoder:
         with torch.cuda.device(_dev()), torch.cuda.stream(main):
             return self.decompress(payloads, h, w)  # guarded calls
 
+    # (events are created with blocking=True: a host thread that waits for one sleeps instead of spinning on a core --
+    #  on a CPU share of 16 per GPU the spinning waiters took cycles from the coder pools)
     def _h2d_stream(self):
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(_dev())
@@ -203,7 +228,7 @@ class SlideCoder:
             n, C = sym.size(0), sym.size(1)
             hw = sym.numel() // (n * C)
             pin = self._pin(('a', k % (depth + 1)), (n, C, hw), torch.int32)
-            ready = torch.cuda.Event()
+            ready = torch.cuda.Event(blocking=True)
             ready.record(main)
             return pin, ready, sym, guard, t
 
@@ -215,7 +240,7 @@ class SlideCoder:
             return pin
 
         def encode(pulled):
-            return self.eb.encode_symbols(pulled.result().numpy(), self.coder_threads)
+            return self.eb.encode_symbols(pulled.result().numpy(), self.encode_threads)
 
         with ThreadPoolExecutor(max_workers=1) as d2h_pool, ThreadPoolExecutor(max_workers=1) as pool:
             inflight = []
@@ -245,20 +270,20 @@ class SlideCoder:
             key = ('d', k % (depth + 2))
             back = self._pin(key, (len(payloads), C, lh * lw), torch.int32)
             self._wait_free(key)  # the H2D that last read this buffer
-            self.eb.decode_symbols(payloads, lh * lw, self.coder_threads, out=back.numpy())
+            self.eb.decode_symbols(payloads, lh * lw, self.decode_threads, out=back.numpy())
             return key, back
 
         def synth(item):
             key, back = item
             with torch.cuda.stream(up):
                 sym = back.to(_dev(), non_blocking=True)
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(blocking=True)
                 ev.record(up)
             self._busy[key] = ev
             main.wait_event(ev)
             sym.record_stream(main)
             rec, guard = self.dec.forward_symbols_u8(sym.reshape(sym.size(0), C, lh, lw), self.eb, defer=True)
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(blocking=True)
             done.record(main)
             return rec, guard, done
 
@@ -346,7 +371,7 @@ class SlideCoder:
             n, C = sym.size(0), sym.size(1)
             hw = sym.numel() // (n * C)
             pin = self._pin(('a', k % (DEPTH + 1)), (n, C, hw), torch.int32)  # in use until encode(k) is done
-            ready = torch.cuda.Event()
+            ready = torch.cuda.Event(blocking=True)
             ready.record(main)
             return k, pin, ready, hw, sym, guard
 
@@ -359,7 +384,7 @@ class SlideCoder:
             _lib.check(_lib.lib().cae_copy_to_host(pin.data_ptr(), sym.data_ptr(), sym.numel() * 4))
             del sym
             t0 = time.perf_counter()
-            payloads = self.eb.encode_symbols(pin.numpy(), self.coder_threads)
+            payloads = self.eb.encode_symbols(pin.numpy(), self.encode_threads, packed=not keep_payloads)
             return k, payloads, hw, pin.shape, time.perf_counter() - t0
 
         def host_decode(enc_future):
@@ -368,7 +393,7 @@ class SlideCoder:
             # decode straight into pinned memory; the set is free again once H2D(k) has run (DEPTH + 2 sets: the decode
             # worker may be DEPTH batches ahead of the synthesis whose H2D is still queued)
             back = self._pin(('d', k % (DEPTH + 2)), shape, torch.int32)
-            self.eb.decode_symbols(payloads, hw, self.coder_threads, out=back.numpy())
+            self.eb.decode_symbols(payloads, hw, self.decode_threads, out=back.numpy())
             return payloads, back, te, time.perf_counter() - t1
 
         def stage_d(k, payloads, back):
@@ -376,7 +401,7 @@ class SlideCoder:
             n, h, w, c = t.shape
             with torch.cuda.stream(copy_up):  # H2D beside the kernels of the main stream
                 sym = back.to(dev, non_blocking=True)
-                up = torch.cuda.Event()
+                up = torch.cuda.Event(blocking=True)
                 up.record(copy_up)
             main.wait_event(up)
             sym.record_stream(main)
@@ -384,7 +409,9 @@ class SlideCoder:
             # dequantiser fused into the layout conversion in front of the first synthesis layer
             rec, guard = self.dec.forward_symbols_u8(sym.reshape(n, self.eb.channels, lh, lw), self.eb, defer=True)
             sse = self.tile_sse(rec, t)
-            return sse, [len(p) + 16 for p in payloads], h * w * c, guard, (k, payloads)
+            nbytes = ([payloads.nbytes(i) + 16 for i in range(len(payloads))] if hasattr(payloads, 'nbytes')
+                      else [len(p) + 16 for p in payloads])
+            return sse, nbytes, h * w * c, guard, (k, payloads)
 
         pending = []  # (sse tensor on GPU, nbytes list, samples)
         # two host workers: batch k+1 is range-encoded while batch k is decoded

@@ -294,6 +294,8 @@ int cae_t_colsum(const void *g16, long pixels, int cp, float *out, void *stream)
  * Streams are coded independently (one per tile), in parallel on `threads` host threads
  * (0 = $CAE_CODER_THREADS, else min(CPUs of this process, 16)).  Symbol order inside a stream is (c, y, x) raster; the CDF row
  * of a symbol is its channel c. */
+/* CPUs this process may keep busy: affinity mask, capped by the cgroup CPU quota, divided by LOCAL_WORLD_SIZE. */
+int cae_cpu_budget(void);
 /* Size of the coder pool a cae_rans_*_batch call with `threads` = requested and n_streams streams uses. */
 int cae_coder_threads(int requested, int n_streams);
 
@@ -303,6 +305,10 @@ int cae_pmf_to_quantized_cdf(const float *pmf_host, int n, int precision, uint32
  * cae_free each) holds stream i and out_lens[i] its byte length. */
 int cae_rans_encode_batch(cae_model_t *m, const int32_t *symbols_host, int n_streams, int hw,
                           uint8_t **out_bufs, size_t *out_lens, int threads);
+/* The same streams in ONE library-allocated buffer (cae_free): stream i = out_buf[offsets[i] .. offsets[i+1]),
+ * offsets has n_streams + 1 entries.  (The batched drivers hand the streams on without per-stream copies.) */
+int cae_rans_encode_packed(cae_model_t *m, const int32_t *symbols_host, int n_streams, int hw, uint8_t **out_buf,
+                           size_t *offsets, int threads);
 /* bufs[i]/lens[i]: stream i.  symbols_host out: (n_streams, channels, hw) int32. */
 int cae_rans_decode_batch(cae_model_t *m, const uint8_t *const *bufs, const size_t *lens, int n_streams,
                           int hw, int32_t *symbols_host, int threads);
