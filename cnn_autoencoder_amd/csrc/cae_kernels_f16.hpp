@@ -236,9 +236,18 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
     constexpr int PAD = KS / 2;
     constexpr int TX = 16, TY = 16;
     constexpr int WH = 2 * TX + KS - 2;
-    constexpr int PLANE_PIECES = TY * WH;          // 16-byte pieces per (plane, half)
-    constexpr int HALO_PIECES = 4 * PLANE_PIECES;  // [pl][hl][row][x]
-    constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;
+    // LDS image of a stage's halo.  The tile's input columns are 2 ox0 - PAD .. 2 ox0 + 32 + (PAD - 1): the 32 columns
+    // from 2 ox0 on are one ALIGNED 32-pixel group of the C8S rows (512 contiguous bytes per plane, half and row), the
+    // other KS - 2 are strays to its left and right.  With all WH columns in one row-major image every LDS-DMA
+    // instruction straddled row ends and touched 10-12 partly used cache lines (profiles/r01_experiments.md: 28 cycles
+    // per staged halo KiB against 9 for the contiguous weights).  Now the aligned columns form their own image
+    // [pl][hl][row][32] -- one instruction = two whole 512-byte runs = 8 full lines -- and each stray column is one
+    // instruction of its own ([pl][hl][row], 64 pieces).
+    constexpr int NSTRAY = WH - 32;                // = KS - 2: PAD to the left, PAD - 1 to the right
+    constexpr int AL_INSTR = 4 * TY * 32 / 64;     // aligned part
+    constexpr int AL_BYTES = AL_INSTR * 1024;
+    constexpr int HALO_INSTR = AL_INSTR + NSTRAY;  // (4 * TY = 64 pieces per stray column)
+    static_assert(TY == 16 && TX == 16, "the halo image assumes 16 x 16 tiles");
     constexpr int W_INSTR = KS * CT * 2;
     constexpr int W_BYTES = W_INSTR * 1024;
     constexpr int G_BYTES = GDN ? CT * 4096 : 0;
@@ -263,13 +272,21 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
     unsigned hoff[MAXP][KS];
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-        int pc = (wave + i * NW) * 64 + lane;
-        pc = pc < HALO_PIECES ? pc : HALO_PIECES - 1;
-        const int plhl = pc / PLANE_PIECES;
-        const int rem = pc - plhl * PLANE_PIECES;
-        const int r = rem / WH, x = rem - r * WH;
+        const int j = wave + i * NW;
+        int plhl, r, c;  // (plane, half), halo row, halo column of this lane's piece in instruction j
+        if (j < AL_INSTR) {
+            const int pc = j * 64 + lane;
+            plhl = pc >> 9;
+            r = (pc >> 5) & 15;
+            c = PAD + (pc & 31);
+        } else {
+            const int js = j - AL_INSTR < NSTRAY ? j - AL_INSTR : NSTRAY - 1;
+            plhl = lane >> 4;
+            r = lane & 15;
+            c = js < PAD ? js : 32 + js;
+        }
         const unsigned base = (unsigned)(plhl >> 1) * (unsigned)plane_bytes + (unsigned)(plhl & 1) * 512u +
-                              c8s_piece<false>(reflect_idx(2 * ox0 - PAD + x, p.W));
+                              c8s_piece<false>(reflect_idx(2 * ox0 - PAD + c, p.W));
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
             hoff[i][ky] = base + (unsigned)reflect_idx(2 * (oy0 + r) - PAD + ky, p.H) *
@@ -303,10 +320,23 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) init_acc<CT>(acc[pt], p.bias, h, 0.0f);
 
-    // B operand of (column tile pt, tap kx): halo [pl = h][hl][row 4w + 2pt + (m>>4)][2(m&15) + kx]
-    const int b_off = W_BYTES + (((2 * h) * TY + 2 * PT * wave + (m >> 4)) * WH + 2 * (m & 15)) * 16;
-    constexpr int B_HL = PLANE_PIECES * 16;  // hi -> lo
-    constexpr int B_PT = 2 * WH * 16;        // column tile 0 -> 1 (two rows down)
+    // B operand of (column tile pt, tap kx): plane h, halo row 2 PT w + 2 pt + (m>>4), halo column 2(m&15) + kx --
+    // in the aligned image or in a stray column's, decided per lane and tap
+    int b_off[KS], b_hl[KS], b_pt[KS];  // byte offset (hi half, column tile 0), hi -> lo, column tile 0 -> 1
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+        const int c = 2 * (m & 15) + kx, row = 2 * PT * wave + (m >> 4);
+        if (c >= PAD && c < PAD + 32) {
+            b_off[kx] = W_BYTES + (((2 * h) * TY + row) * 32 + c - PAD) * 16;
+            b_hl[kx] = TY * 32 * 16;
+            b_pt[kx] = 2 * 32 * 16;
+        } else {
+            const int js = c < PAD ? c : c - 32;
+            b_off[kx] = W_BYTES + AL_BYTES + ((js * 4 + 2 * h) * TY + row) * 16;
+            b_hl[kx] = TY * 16;
+            b_pt[kx] = 2 * 16;
+        }
+    }
     int sc = 0;
 
     issue_stage(0, std::integral_constant<int, 0>{}, smem);
@@ -333,7 +363,6 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
             }
 #endif
             const char *wb = cur + lane * 16;
-            const char *hb = cur + b_off;
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
 #ifdef CAE_EXP_F16C_ONETAP
@@ -344,8 +373,8 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
                 f16x8 bh[PT], bl[PT];
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) {
-                    bh[pt] = *(const f16x8 *)(hb + pt * B_PT + kxr * 16);
-                    bl[pt] = *(const f16x8 *)(hb + pt * B_PT + kxr * 16 + B_HL);
+                    bh[pt] = *(const f16x8 *)(cur + b_off[kxr] + pt * b_pt[kxr]);
+                    bl[pt] = *(const f16x8 *)(cur + b_off[kxr] + pt * b_pt[kxr] + b_hl[kxr]);
                 }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
@@ -601,9 +630,15 @@ struct DeconvGeomF16 {
     static constexpr int DLO = -((P + 1) / 2), DHI = (KS - 1 - P) / 2;
     static constexpr int WH = 32 + DHI - DLO;
     static constexpr int ROWS = NW * PT;  // input rows per block
-    static constexpr int PLANE_PIECES = ROWS * WH;
-    static constexpr int HALO_PIECES = 4 * PLANE_PIECES;
-    static constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;
+    // halo image (as in conv_s2_f16_kernel): the 32 columns ix0 .. ix0 + 31 are whole 256-byte runs of the C8SP rows
+    // and form an aligned image [pl][hl][row][32]; the DHI columns to the left and -DLO to the right are strays,
+    // [stray][pl][hl][row], packed into one more LDS-DMA instruction
+    static constexpr int NSTRAY = WH - 32;
+    static constexpr int AL_INSTR = 4 * ROWS * 32 / 64;
+    static constexpr int AL_BYTES = AL_INSTR * 1024;
+    static constexpr int STRAY_INSTR = (NSTRAY * 4 * ROWS + 63) / 64;
+    static constexpr int HALO_INSTR = AL_INSTR + STRAY_INSTR;
+    static_assert((4 * ROWS * 32) % 64 == 0 && 64 % (4 * ROWS) == 0, "halo image assumes 4, 8 or 16 input rows per block");
     static constexpr int W_INSTR = KS * CT * 2;
     static constexpr int W_BYTES = W_INSTR * 1024;
     static constexpr int G_BYTES = IGDN ? CT * 4096 : 0;
@@ -643,12 +678,11 @@ __device__ __forceinline__ void deconv_issue_f16(const LayerArgs &p, const char 
 template <int KS, int CT, int NW, int PT, bool IGDN, int PY>
 __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char *in_n, size_t plane_bytes, char *smem,
                                                  int &sc, const int *hrow, const long *hbase, int wave, int lane,
-                                                 int b_off, int n, int iy, int ix) {
+                                                 const int (&b_off)[KS], const int (&b_hl)[KS], const int (&b_pt)[KS],
+                                                 int n, int iy, int ix) {
     using G = DeconvGeomF16<KS, CT, NW, PT, IGDN>;
     constexpr int P = G::P;
     constexpr int STAGE_BYTES = G::STAGE_BYTES;
-    constexpr int B_HL = G::PLANE_PIECES * 16;
-    constexpr int B_PT = G::WH * 16;  // next input row of this wave
     const int h = lane >> 5;
     const int NS = p.cci * G::nky(PY);
     f32x16 acc[2][PT][CT];  // [px][row tile][ct]
@@ -672,17 +706,15 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
         }
 #endif
         const char *wb = cur + lane * 16;
-        const char *hb = cur + b_off;
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
             if (PT > 1) __builtin_amdgcn_sched_barrier(0);  // bound operand live ranges to one tap (register budget)
             const int px = (kx + P) & 1;
-            const int dx = (kx - P - px) / 2;
             f16x8 bh[PT], bl[PT];
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
-                bh[pt] = *(const f16x8 *)(hb + pt * B_PT - dx * 16);
-                bl[pt] = *(const f16x8 *)(hb + pt * B_PT - dx * 16 + B_HL);
+                bh[pt] = *(const f16x8 *)(cur + b_off[kx] + pt * b_pt[kx]);
+                bl[pt] = *(const f16x8 *)(cur + b_off[kx] + pt * b_pt[kx] + b_hl[kx]);
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
@@ -752,12 +784,21 @@ __global__ void __launch_bounds__(NW * 64, NW * PT <= 4 ? 2 : 1) deconv_s2_f16_k
     long hbase[G::MAXP];  // byte offset of (plane-in-chunk, half, column) inside the chunk, < 0: outside
 #pragma unroll
     for (int i = 0; i < G::MAXP; ++i) {
-        int pc = (wave + i * NW) * 64 + lane;
-        pc = pc < G::HALO_PIECES ? pc : G::HALO_PIECES - 1;
-        const int plhl = pc / G::PLANE_PIECES;
-        const int rem = pc - plhl * G::PLANE_PIECES;
-        const int r = rem / G::WH, x = rem - r * G::WH;
-        const int ix = ix0 + x - G::DHI;
+        const int j = wave + i * NW;
+        int plhl, r, c;  // (plane, half), halo row, halo column of this lane's piece in instruction j
+        if (j < G::AL_INSTR) {
+            const int pc = j * 64 + lane;
+            plhl = pc / (G::ROWS * 32);
+            r = (pc / 32) % G::ROWS;
+            c = G::DHI + (pc & 31);
+        } else {
+            int js = (j - G::AL_INSTR) * (64 / (4 * G::ROWS)) + lane / (4 * G::ROWS);
+            js = js < G::NSTRAY ? js : G::NSTRAY - 1;
+            plhl = (lane / G::ROWS) & 3;
+            r = lane % G::ROWS;
+            c = js < G::DHI ? js : 32 + js;
+        }
+        const int ix = ix0 + c - G::DHI;
         hrow[i] = iy0 + r;
         hbase[i] = (ix >= 0 && ix < p.W) ? (long)(plhl >> 1) * (long)((size_t)p.H * c8s_row_bytes<true>(p.W)) +
                                                (long)c8s_piece<true>(ix) + (plhl & 1) * 512
@@ -765,15 +806,30 @@ __global__ void __launch_bounds__(NW * 64, NW * PT <= 4 ? 2 : 1) deconv_s2_f16_k
     }
     const size_t plane_bytes = (size_t)p.H * c8s_row_bytes<true>(p.W);  // input rows are C8SP
     const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
-    // B operand: halo [pl = h][hl][row = PT*wave + pt][x = m + DHI - dx]
-    const int b_off = G::W_BYTES + (((2 * h) * G::ROWS + PT * wave) * G::WH + m + G::DHI) * 16;
+    // B operand of tap kx: plane h, halo row PT*wave + pt, halo column m + DHI - dx(kx): aligned image or a stray's
+    int b_off[KS], b_hl[KS], b_pt[KS];
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+        const int pxk = (kx + G::P) & 1, dx = (kx - G::P - pxk) / 2;
+        const int c = m + G::DHI - dx, row = PT * wave;
+        if (c >= G::DHI && c < G::DHI + 32) {
+            b_off[kx] = G::W_BYTES + (((2 * h) * G::ROWS + row) * 32 + c - G::DHI) * 16;
+            b_hl[kx] = G::ROWS * 32 * 16;
+            b_pt[kx] = 32 * 16;
+        } else {
+            const int js = c < G::DHI ? c : c - 32;
+            b_off[kx] = G::W_BYTES + G::AL_BYTES + ((js * 4 + 2 * h) * G::ROWS + row) * 16;
+            b_hl[kx] = G::ROWS * 16;
+            b_pt[kx] = 16;
+        }
+    }
     const int iy = iy0 + PT * wave, ix = ix0 + m;
     int sc = 0;
     deconv_issue_f16<KS, CT, NW, PT, IGDN, 0>(p, in_n, plane_bytes, 0, smem, hrow, hbase, wave, lane);
-    deconv_phase_f16<KS, CT, NW, PT, IGDN, 0>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, n, iy,
-                                              ix);
-    deconv_phase_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, n, iy,
-                                              ix);
+    deconv_phase_f16<KS, CT, NW, PT, IGDN, 0>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, b_hl, b_pt,
+                                              n, iy, ix);
+    deconv_phase_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, b_hl, b_pt,
+                                              n, iy, ix);
 }
 
 // =================================================================================================

@@ -340,7 +340,13 @@ def _track_inputs(track, units, synthesis: bool):
 
 
 def needs_grad(module: nn.Module, x: torch.Tensor) -> bool:
-    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+    """The differentiable track functions run when the module is in TRAINING mode and autograd is recording
+    (train_cae_ms.py:183-187 puts the trainable modules in train(), the others in eval() under fixed_module's no_grad).
+    In eval mode the inference kernels run whether or not autograd is enabled: the reference's codec.encode forgets
+    torch.no_grad() (_autoencoders.py:539-555) and must keep its inference numerics."""
+    if not (module.training and torch.is_grad_enabled()):
+        return False
+    return x.requires_grad or any(p.requires_grad for p in module.parameters())
 
 
 def analysis_forward(track, x: torch.Tensor) -> torch.Tensor:
