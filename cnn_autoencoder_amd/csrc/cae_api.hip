@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -218,6 +219,29 @@ static std::vector<_Float16> pack_last_f16(const float *w, int cin, int cout, in
     return out;
 }
 
+// last layer as a product map (cae_kernels_f16.hpp, pmap): [jt][s][hl][lane][8]:
+//   A(row = lane&31 = 3 tap + c, k = 32jt + row(8s+e) + 4(lane>>5)) = W[cin = k][c][ky][kx], tap = 3 ky + kx  (k = 3)
+static std::vector<_Float16> pack_pmap_f16(const float *w, int cin, int cout) {
+    const int njt = (cin + 31) / 32;
+    std::vector<_Float16> out((size_t)njt * 2 * 2 * 512, (_Float16)0.0f);
+    for (int jt = 0; jt < njt; ++jt)
+        for (int s2 = 0; s2 < 2; ++s2)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * s2 + e;
+                    const int row = lane & 31, tap = row / 3, c = row % 3;
+                    const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = 0.0f;
+                    if (tap < 9 && c < cout && j < cin) v = w[((size_t)j * cout + c) * 9 + tap];
+                    _Float16 hi, lo;
+                    split_half(v, hi, lo);
+                    const size_t base = (((size_t)jt * 2 + s2) * 2) * 512;
+                    out[base + (size_t)lane * 8 + e] = hi;
+                    out[base + 512 + (size_t)lane * 8 + e] = lo;
+                }
+    return out;
+}
+
 static int upload_raw(const void *src, size_t bytes, void **dev) {
     if (*dev) {
         (void)hipFree(*dev);
@@ -312,6 +336,7 @@ Model::~Model() {
             if (l.wp16) (void)hipFree(l.wp16);
             if (l.gp16) (void)hipFree(l.gp16);
             if (l.wp_edge16) (void)hipFree(l.wp_edge16);
+            if (l.wp_pmap16) (void)hipFree(l.wp_pmap16);
         }
     for (int i = 0; i < 4; ++i)
         if (ws[i]) (void)hipFree(ws[i]);
@@ -559,6 +584,14 @@ int cae_model_set_layer(cae_model_t *mm, int track, int index, int cin, int cout
         } else if (track == CAE_SYNTHESIS && index == m->L - 1 && cout <= 4 && beta == nullptr) {
             auto e16 = pack_last_f16(w, cin, cout, m->ks);
             if ((rc = upload_raw(e16.data(), e16.size() * sizeof(_Float16), &l.wp_edge16))) return rc;
+        }
+        if (l.wp_pmap16) {
+            (void)hipFree(l.wp_pmap16);
+            l.wp_pmap16 = nullptr;
+        }
+        if (track == CAE_SYNTHESIS && index == m->L - 1 && m->ks == 3 && cout <= 3 && beta == nullptr) {
+            auto pm16 = pack_pmap_f16(w, cin, cout);
+            if ((rc = upload_raw(pm16.data(), pm16.size() * sizeof(_Float16), &l.wp_pmap16))) return rc;
         }
         auto w16 = pack_weights_f16(w, track == CAE_SYNTHESIS, cin, cout, m->ks, ct);
         if ((rc = upload_raw(w16.data(), w16.size() * sizeof(_Float16), &l.wp16))) return rc;
@@ -932,12 +965,35 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
     HIP_TRY(hipGetLastError());
     prof.end();
 
+    // Product-map form of the last two layers (cae_kernels_f16.hpp, pmap): layer L-2 stores the products of its output
+    // with the last layer's weights, the last layer is a gather.  Needs the f16x3 transposed-convolution kernel for
+    // layer L-2, k = 3, at most 3 image channels, and nobody asking for layer L-2's own output (bridges / colours).
+    bool use_pmap = false;
+    if (f16 && m->L >= 2 && m->ks == 3 && getenv("CAE_NO_PMAP") == nullptr) {
+        const Layer &lp = m->dec[m->L - 2], &ll = m->dec[m->L - 1];
+        // (conv_f16-style LDS budget: two 33-KiB stages + the transpose buffers fit for k = 3 and up to 128 channels)
+        use_pmap = ll.wp_pmap16 && !ll.gdn && ll.stages.empty() && lp.stages.empty() && lp.ct <= 4 && lp.cout == ll.cin &&
+                   !(bridges && bridges[m->L - 2]) && !(colors && colors[m->L - 2]);
+    }
+    if (use_pmap) maxact = std::max(maxact, (size_t)n * (lh << (m->L - 1)) * (lw << (m->L - 1)) * 128);
+    if (use_pmap && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
+
     const float *cur = (const float *)m->ws[0];
     int cur_planes = p0, ch = lh, cw = lw;
     int cur_idx = 0;
     for (int i = 0; i < m->L; ++i) {
         const Layer &l = m->dec[i];
         const bool last = i == m->L - 1;
+        if (use_pmap && last) {  // the gather half of the product map
+            prof.begin();
+            const int gtx = (cw + 15) / 16, gty = (ch + 15) / 16;
+            hipLaunchKernelGGL(pmap_gather_kernel, dim3((unsigned)((size_t)n * gtx * gty)), dim3(256), 0, st, cur,
+                               (const float *)l.bias, out, n, ch, cw, l.cout, fmt == CAE_FMT_U8_HWC ? OUT_U8HWC : OUT_NCHW, gtx,
+                               gty);
+            HIP_TRY(hipGetLastError());
+            prof.end();
+            break;
+        }
         if (!l.stages.empty() && (rc = run_stages(m, l, true, n, ch, cw, cur, cur_idx, cur_planes, st))) return rc;
         LayerArgs a{};
         a.in = cur;
@@ -963,6 +1019,10 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
         a.tiles_x = (cw + 31) / 32;
         a.tiles_y = (ch + CAE_DECONV_NW - 1) / CAE_DECONV_NW;
         a.outfmt = last ? (fmt == CAE_FMT_U8_HWC ? OUT_U8HWC : OUT_NCHW) : OUT_C8;
+        if (use_pmap && i == m->L - 2) {
+            a.outfmt = OUT_PMAP;
+            a.pm = m->dec[m->L - 1].wp_pmap16;
+        }
         prof.begin();
         if (f16) {
             a.gp = (const float *)l.gp16;

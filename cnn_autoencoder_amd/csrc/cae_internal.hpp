@@ -39,6 +39,7 @@ struct Layer {
     void *wp16 = nullptr;      // f16x3 path: packed hi/lo weights
     void *gp16 = nullptr;      // f16x3 path: packed hi/lo gamma
     void *wp_edge16 = nullptr; // f16x3 path: packed weights of the first-conv / last-deconv kernel
+    void *wp_pmap16 = nullptr; // f16x3 path, last synthesis layer (k = 3, cout <= 3): its weights as the product map
     bool f16_bad = false;      // a weight / gamma entry is not finite in f16: the model runs on the fp32 kernels
 };
 

@@ -34,7 +34,9 @@ namespace cae {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum OutFmt { OUT_C8 = 0, OUT_NCHW = 1, OUT_U8HWC = 2, OUT_SYM = 3 };  // OUT_SYM: NCHW int32 round(v - median_c)
+enum OutFmt { OUT_C8 = 0, OUT_NCHW = 1, OUT_U8HWC = 2, OUT_SYM = 3, OUT_PMAP = 4 };  // OUT_SYM: NCHW int32 round(v - median_c)
+// OUT_PMAP (f16x3 synthesis, second-to-last layer): instead of its activations the layer stores, per pixel, their products
+// with every (tap, output channel) column of the LAST layer's weights: fp32 [N][OH][OW][32] (cae_kernels_f16.hpp, pmap)
 
 struct LayerArgs {
     const float *in;    // C8 [N][in_planes][H][W][8]
@@ -56,6 +58,7 @@ struct LayerArgs {
     int res_planes;     // planes of `res` (the unit input may carry fewer padded planes than the output)
     int post_act;       // activation after the residual sum
     const float *medians;  // >= 192 floats: per-channel medians (OUT_SYM, fused quantiser) or zeros; never null
+    const void *pm;     // OUT_PMAP: packed weights of the last layer [jt][s][hl][64 lanes][8 f16]
     int *flag;          // f16x3 range guard: set to 1 when a value leaves the f16 range (never null on the f16x3 path)
 };
 

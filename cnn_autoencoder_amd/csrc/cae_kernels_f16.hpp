@@ -618,6 +618,153 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
     }
 }
 
+// ---- last-layer product map ("pmap") ------------------------------------------------------------------------
+// The last synthesis layer (ConvTranspose2d 128 -> 3, _autoencoders.py:204-211) reads its 128-channel input once per
+// tile: 134 MB for 0.9 GMAC, the most memory-bound kernel of the step.  Its channel contraction commutes with the
+// spatial gather: out[2a+py][2b+px][c] = bias[c] + sum_{d,dx} P[a-d][b-dx][tap(d,dx)][c] with
+// P[pixel][tap][c] = sum_j x[pixel][j] W[j][c][tap] a POINTWISE linear map of the input pixel.  So the layer that produces
+// x applies that map to its accumulator tile (one more MFMA chain, the accumulators as B operand in their own row
+// order exactly as in the fused IGDN) and stores 27 (padded to 32) fp32 values per pixel instead of 128 split
+// channels: 128 B instead of 512 B written, and the last layer becomes a 4-term gather (pmap_gather_kernel) that
+// reads 128 B per pixel instead of 512 B.  Same fp32-class arithmetic (f16x3 products, fp32 accumulation); only the
+// summation order of the last layer changes.
+//   packed map: [jt][s(2)][hl(2)][64 lanes][8 f16]: A(row = lane&31 = 3 tap + c, k = 32jt + row(8s + e) + 4(lane>>5))
+//   map in HBM: fp32 [N][OH][2][OW/2][32]: rows split by pixel parity (as C8SP), because a sub-pixel phase produces every
+//   second pixel: the 32 pixels of a wave are then 32 consecutive 128-byte records.
+__host__ __device__ __forceinline__ size_t pmap_record(int n, int OH, int OW, int oy, int ox) {
+    return ((((size_t)n * OH + oy) * 2 + (ox & 1)) * (OW >> 1) + (ox >> 1)) * 32;
+}
+
+// j0: index (in its parity row) of the wave's first pixel; tbuf: 4 KiB of LDS private to the wave.  The accumulator
+// layout gives every lane four scattered 16-byte pieces of its pixel's record; written like that (16 bytes per lane at a
+// 128-byte stride) the store cost 0.25 ms of deconv3's 3.07 (CAE_EXP_PMAP_NOSTORE).  So the tile is transposed through
+// LDS (XOR-swizzled pieces: conflict-free both ways) and leaves as four instructions of 1 KiB contiguous each.
+template <int CT>
+__device__ __forceinline__ void store_pmap_f16(const f32x16 (&y)[CT], const LayerArgs &p, char *tbuf, int n, int oy, int par,
+                                               int j0, int lane, bool row_valid) {
+    const int h = lane >> 5, m = lane & 31;
+    f32x16 pm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pm[r] = 0.0f;
+    float mx = 0.0f;
+    const char *ab = (const char *)p.pm + lane * 16;
+#pragma unroll
+    for (int jt = 0; jt < CT; ++jt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 sh, sl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = y[jt][8 * s + e];
+                mx = __builtin_fmaxf(mx, __builtin_fabsf(v));
+                _Float16 a, b;
+                split_f16(v, a, b);
+                sh[e] = a;
+                sl[e] = b;
+            }
+            const f16x8 ah = *(const f16x8 *)(ab + ((jt * 2 + s) * 2 + 0) * 1024);
+            const f16x8 al = *(const f16x8 *)(ab + ((jt * 2 + s) * 2 + 1) * 1024);
+            pm = mfma3(ah, al, sh, sl, pm);
+        }
+    raise_if_over(mx, p.flag);
+#ifdef CAE_EXP_PMAP_NOSTORE  // timing-only ablation: the map is computed but not written (wrong results)
+    if (p.N > 0) return;
+#endif
+    // D: register r = map row acc_row(r) + 4h: lane (m, h) holds pieces q = 2g + h (g = 0..3) of pixel m's record
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {pm[4 * g], pm[4 * g + 1], pm[4 * g + 2], pm[4 * g + 3]};
+        *(f32x4 *)(tbuf + m * 128 + (((2 * g + h) ^ (m & 7)) * 16)) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int half_w = p.OW >> 1;
+    float *row = (float *)p.out + ((((size_t)n * p.OH + oy) * 2 + par) * half_w) * 32;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int px = (lane >> 3) + 8 * it, q = lane & 7;
+        const f32x4 v = *(const f32x4 *)(tbuf + px * 128 + ((q ^ (px & 7)) * 16));
+        if (row_valid && j0 + px < half_w) *(f32x4 *)(row + (size_t)(j0 + px) * 32 + 4 * q) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// out[n][2a+py][2b+px][c] = bias[c] + sum over (d, dx) of P[a-d][b-dx][(2d+py+1)*3 + (2dx+px+1)][c]   (k = 3)
+// block = 16 x 16 input pixels (a, b) -> 32 x 32 output pixels.  The 17 x 17 records (one halo row / column) are staged
+// in LDS with coalesced 16-byte loads (record pitch 33 floats: conflict-free), every thread sums the <= 4 terms of its
+// 2 x 2 output pixels, and uint8 output rows leave through LDS as whole dwords (the per-thread byte stores of the first
+// version made this kernel as slow as the layer it replaces).  uint8 HWC (x255, clip, truncate) or fp32 NCHW.
+static __global__ void __launch_bounds__(256) pmap_gather_kernel(const float *pm, const float *bias, void *out, int N, int H,
+                                                               int W, int cout, int fmt, int tiles_x, int tiles_y) {
+    constexpr int T = 16, R = T + 1, PITCH = 33;
+    __shared__ float rec[R * R * PITCH];
+    __shared__ __attribute__((aligned(4))) uint8_t orow[2 * T][2 * T * 3 + 4];
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int a0 = ty * T, b0 = tx * T;
+    for (int i = threadIdx.x; i < R * R * 8; i += 256) {
+        const int q = i & 7, r = i >> 3;
+        const int ra = r / R, rb = r - ra * R;
+        const int a = a0 + ra, b = b0 + rb;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};  // records outside the image contribute nothing
+        if (a < H && b < W) v = *(const f32x4 *)(pm + pmap_record(n, H, W, a, b) + 4 * q);
+        float *d = rec + r * PITCH + 4 * q;
+        d[0] = v[0];
+        d[1] = v[1];
+        d[2] = v[2];
+        d[3] = v[3];
+    }
+    __syncthreads();
+    const int la = threadIdx.x >> 4, lb = threadIdx.x & 15;
+    const int a = a0 + la, b = b0 + lb;
+    const float *p00 = rec + (la * R + lb) * PITCH, *p01 = p00 + PITCH, *p10 = p00 + R * PITCH, *p11 = p10 + PITCH;
+    const int OH = 2 * H, OW = 2 * W;
+    const bool u8 = fmt == OUT_U8HWC;
+    for (int c = 0; c < cout; ++c) {
+        const float bs = bias ? bias[c] : 0.0f;
+        // tap t = 3 ky + kx; py = 0: ky = 1 at row a; py = 1: ky = 2 at row a and ky = 0 at row a + 1 (same for columns)
+        const float o00 = bs + p00[12 + c];
+        const float o01 = bs + p00[15 + c] + p01[9 + c];
+        const float o10 = bs + p00[21 + c] + p10[3 + c];
+        const float o11 = bs + p00[24 + c] + p01[18 + c] + p10[6 + c] + p11[c];
+        if (u8) {
+            orow[2 * la][(2 * lb) * cout + c] = clip_u8(o00 * 255.0f);
+            orow[2 * la][(2 * lb + 1) * cout + c] = clip_u8(o01 * 255.0f);
+            orow[2 * la + 1][(2 * lb) * cout + c] = clip_u8(o10 * 255.0f);
+            orow[2 * la + 1][(2 * lb + 1) * cout + c] = clip_u8(o11 * 255.0f);
+        } else if (a < H && b < W) {
+            float *o = (float *)out + (((size_t)n * cout + c) * OH + 2 * a) * OW + 2 * b;
+            o[0] = o00;
+            o[1] = o01;
+            o[OW] = o10;
+            o[OW + 1] = o11;
+        }
+    }
+    if (!u8) return;
+    __syncthreads();
+    // rows of 2T pixels x cout bytes; whole dwords when the row segment is dword-aligned and inside the image
+    const int row_bytes = 2 * T * cout;
+    const int valid_rows = min(2 * T, OH - 2 * a0), valid_bytes = min(2 * T, OW - 2 * b0) * cout;
+    uint8_t *obase = (uint8_t *)out + (((size_t)n * OH + 2 * a0) * OW + 2 * b0) * cout;
+    const bool dwords = ((((size_t)OW * cout) & 3) == 0) && (((uintptr_t)obase & 3) == 0) && (row_bytes & 3) == 0 &&
+                        valid_bytes == row_bytes;
+    if (dwords) {
+        const int per_row = row_bytes / 4;
+        for (int i = threadIdx.x; i < valid_rows * per_row; i += 256) {
+            const int r = i / per_row, q = i - r * per_row;
+            *(uint32_t *)(obase + (size_t)r * OW * cout + 4 * q) = *(const uint32_t *)(&orow[r][4 * q]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < valid_rows * valid_bytes; i += 256) {
+            const int r = i / valid_bytes, q = i - r * valid_bytes;
+            obase[(size_t)r * OW * cout + q] = orow[r][q];
+        }
+    }
+}
+
 // =================================================================================================
 // deconv_s2_f16_kernel: stride-2 transposed conv (+bias) (+IGDN), f16x3, C8S in.
 //   block = NW waves, wave w owns INPUT row ty0+w, 32 input columns; per output-row parity py two
@@ -739,9 +886,14 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
 
     auto store_px = [&](int x) {
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
-            store_tiles_f16<CT, true>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h,
-                                      (iy + pt) < p.H && ix < p.W);
+        for (int pt = 0; pt < PT; ++pt) {
+            if (p.outfmt == OUT_PMAP)
+                store_pmap_f16<CT>(acc[x][pt], p, smem + 2 * STAGE_BYTES + wave * 4096, n, 2 * (iy + pt) + PY, x,
+                                   ix - (lane & 31), lane, (iy + pt) < p.H);
+            else
+                store_tiles_f16<CT, true>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h,
+                                          (iy + pt) < p.H && ix < p.W);
+        }
     };
     if constexpr (IGDN) {
         // one (px, row tile) at a time: 64 norm accumulators live instead of 128 (register budget);
@@ -756,8 +908,12 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
                     deconv_issue_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, 0, nxt, hrow, hbase, wave, lane);
                 }
             });
-            store_tiles_f16<CT, true>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h,
-                                      (iy + pt) < p.H && ix < p.W);
+            if (p.outfmt == OUT_PMAP)
+                store_pmap_f16<CT>(acc[x][pt], p, smem + 2 * STAGE_BYTES + wave * 4096, n, 2 * (iy + pt) + PY, x,
+                                   ix - (lane & 31), lane, (iy + pt) < p.H);
+            else
+                store_tiles_f16<CT, true>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h,
+                                          (iy + pt) < p.H && ix < p.W);
         });
     } else {
         store_px(0);

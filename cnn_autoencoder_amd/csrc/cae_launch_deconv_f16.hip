@@ -15,19 +15,23 @@ static int launch_deconv_f16_t(const LayerArgs &a, hipStream_t st) {
     constexpr int NW = CAE_DF16_NW, PT = 1;
     using G = DeconvGeomF16<KS, CT, NW, PT, GDN>;
     constexpr int LDS = 2 * G::STAGE_BYTES;
+    constexpr int PMAP_LDS = NW * 4096;  // OUT_PMAP: one 4-KiB transpose buffer per wave behind the stage buffers
     if constexpr (LDS > 160 * 1024) {
         return fail(CAE_ERR_UNSUPPORTED, "f16x3: this kernel_size/channel combination exceeds the LDS; use fp32");
     } else {
         auto kern = deconv_s2_f16_kernel<KS, CT, NW, PT, GDN>;
-        static bool attr_done = false;
-        if (!attr_done) {
-            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            attr_done = true;
+        const bool pmap = a.outfmt == OUT_PMAP;
+        if (pmap && LDS + PMAP_LDS > 160 * 1024) return fail(CAE_ERR_UNSUPPORTED, "product map: LDS exceeded");
+        static int attr_bytes = 0;
+        const int lds = LDS + (pmap ? PMAP_LDS : 0);
+        if (lds > attr_bytes) {
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_bytes = lds;
         }
         LayerArgs b = a;
         b.tiles_y = (a.H + G::ROWS - 1) / G::ROWS;  // input rows per block follow the kernel's wave count
         const unsigned grid = (unsigned)((size_t)b.N * b.tiles_x * b.tiles_y);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, st, b);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, b);
         HIP_TRY(hipGetLastError());
         return CAE_OK;
     }

@@ -53,6 +53,7 @@ for case in range(n_cases):
             enc.cuda(); dec.cuda()
             y = enc.forward_u8(torch.from_numpy(tiles).cuda()).cpu()
             x_r, _ = dec(yq.cuda())
+            u8 = dec.forward_u8(yq.cuda()).cpu()  # codec path (k = 3 GDN models: product-map form of the last two layers)
             # fused quantiser / dequantiser entry points == the unfused calls, bit for bit
             eb = cae.EntropyBottleneck(kw['channels_bn']).eval()
             with torch.no_grad():
@@ -75,6 +76,10 @@ for case in range(n_cases):
     ex = float((x_r[0].cpu() - xr_ref).abs().max() / max(1.0, float(xr_ref.abs().max())))
     assert all((t is None) != kw['multiscale_analysis'] for t in x_r[1:])  # colour layers only with multiscale_analysis
     ok = y.shape == y_ref.shape and ey < 1e-4 and ex < 1e-4
+    if ok and float(xr_ref.abs().max()) < 1e3:  # uint8 epilogue: <= 1 level, rarely, against the truncated reference
+        ref8 = (xr_ref * 255.0).clip(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+        d8 = (u8.int() - ref8.int()).abs()
+        ok = int(d8.max()) <= 1 and float((d8 > 0).float().mean()) < 5e-3
     if case % 100 == 99:
         print(f'... {case + 1} cases, {fails} failures so far, {time.time() - t_start:.0f} s', flush=True)
     if not ok:
