@@ -221,8 +221,8 @@ static std::vector<_Float16> pack_last_f16(const float *w, int cin, int cout, in
 
 // last layer as a product map (cae_kernels_f16.hpp, pmap): [jt][s][hl][lane][8]:
 //   A(row = lane&31 = 3 tap + c, k = 32jt + row(8s+e) + 4(lane>>5)) = W[cin = k][c][ky][kx], tap = 3 ky + kx  (k = 3)
-static std::vector<_Float16> pack_pmap_f16(const float *w, int cin, int cout) {
-    const int njt = (cin + 31) / 32;
+static std::vector<_Float16> pack_pmap_f16(const float *w, int cin, int cout, int njt) {
+    // njt = channel tiles of the PRODUCING layer's accumulators (round_ct(cin): 96 channels live in 4 tiles), zero padded
     std::vector<_Float16> out((size_t)njt * 2 * 2 * 512, (_Float16)0.0f);
     for (int jt = 0; jt < njt; ++jt)
         for (int s2 = 0; s2 < 2; ++s2)
@@ -590,7 +590,7 @@ int cae_model_set_layer(cae_model_t *mm, int track, int index, int cin, int cout
             l.wp_pmap16 = nullptr;
         }
         if (track == CAE_SYNTHESIS && index == m->L - 1 && m->ks == 3 && cout <= 3 && beta == nullptr) {
-            auto pm16 = pack_pmap_f16(w, cin, cout);
+            auto pm16 = pack_pmap_f16(w, cin, cout, round_ct(cin));
             if ((rc = upload_raw(pm16.data(), pm16.size() * sizeof(_Float16), &l.wp_pmap16))) return rc;
         }
         auto w16 = pack_weights_f16(w, track == CAE_SYNTHESIS, cin, cout, m->ks, ct);

@@ -359,7 +359,7 @@ class SlideCoder:
         # all pinned symbol buffers up front (hipHostMalloc of 100 MB costs ~10 ms: not inside the pipeline)
         n0, h0, w0, _ = batches[0].shape
         lh0, lw0 = self.enc.latent_size(h0, w0)
-        for j in range(DEPTH + 1):
+        for j in range(DEPTH + 2):
             self._pin(('a', j), (n0, self.eb.channels, lh0 * lw0), torch.int32)
         for j in range(DEPTH + 2):
             self._pin(('d', j), (n0, self.eb.channels, lh0 * lw0), torch.int32)
@@ -370,19 +370,23 @@ class SlideCoder:
             sym, guard = self.enc.forward_u8_symbols(t, self.eb, defer=True)
             n, C = sym.size(0), sym.size(1)
             hw = sym.numel() // (n * C)
-            pin = self._pin(('a', k % (DEPTH + 1)), (n, C, hw), torch.int32)  # in use until encode(k) is done
+            pin = self._pin(('a', k % (DEPTH + 2)), (n, C, hw), torch.int32)  # in use until encode(k) is done
             ready = torch.cuda.Event(blocking=True)
             ready.record(main)
             return k, pin, ready, hw, sym, guard
 
-        def host_encode(k, pin, ready, hw, sym, guard):
-            # D2H on the DMA engines from this worker thread (cae_copy_to_host): a hipMemcpyAsync here runs as a
-            # blit kernel under PyTorch's HIP runtime and held the main stream up for the whole PCIe transfer
+        def host_pull(k, pin, ready, hw, sym, guard):
+            # D2H on the DMA engines from a worker thread of its own (cae_copy_to_host): a hipMemcpyAsync here runs as a
+            # blit kernel under PyTorch's HIP runtime and held the main stream up for the whole PCIe transfer; in the
+            # encode worker the 2 ms of the copy were serial with the 4-7 ms of range coding and set the step time
             ready.synchronize()
             if guard.overflowed():  # f16x3 range guard: repeat this batch on the fp32 kernels
                 sym = self._redo_analysis(batches[k], main)
             _lib.check(_lib.lib().cae_copy_to_host(pin.data_ptr(), sym.data_ptr(), sym.numel() * 4))
-            del sym
+            return k, pin, hw
+
+        def host_encode(pull_future):
+            k, pin, hw = pull_future.result()
             t0 = time.perf_counter()
             payloads = self.eb.encode_symbols(pin.numpy(), self.encode_threads, packed=not keep_payloads)
             return k, payloads, hw, pin.shape, time.perf_counter() - t0
@@ -415,11 +419,12 @@ class SlideCoder:
 
         pending = []  # (sse tensor on GPU, nbytes list, samples)
         # two host workers: batch k+1 is range-encoded while batch k is decoded
-        with ThreadPoolExecutor(max_workers=1) as enc_pool, ThreadPoolExecutor(max_workers=1) as dec_pool:
+        with ThreadPoolExecutor(max_workers=1) as pull_pool, ThreadPoolExecutor(max_workers=1) as enc_pool, \
+                ThreadPoolExecutor(max_workers=1) as dec_pool:
             futs = {}
 
             def submit(k):
-                futs[k] = dec_pool.submit(host_decode, enc_pool.submit(host_encode, *stage_a(k)))
+                futs[k] = dec_pool.submit(host_decode, enc_pool.submit(host_encode, pull_pool.submit(host_pull, *stage_a(k))))
 
             for k in range(min(DEPTH, K)):
                 submit(k)

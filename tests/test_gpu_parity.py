@@ -551,3 +551,36 @@ def test_cfg3_batch128_256_bitstreams_bit_exact(cae):
     assert np.array_equal(sym.reshape(128, 192, 16, 16), o.symbols(y).numpy())
     rec = codec.decode_batch(bufs)
     assert rec.shape == (128, 256, 256, 3)
+
+
+@pytest.mark.parametrize('cfgkw,shape', [(dict(channels_net=96, channels_bn=72, compression_level=2, bias=True), (2, 12, 64)),
+                                         (dict(channels_net=40, channels_bn=48, compression_level=3), (1, 5, 9)),
+                                         (dict(channels_org=1, channels_net=32, channels_bn=16, compression_level=2), (3, 8, 8)),
+                                         (dict(channels_net=128, channels_bn=192, compression_level=4), (2, 4, 6)),
+                                         (dict(channels_net=64, channels_bn=48, compression_level=3, act_layer_type=None), (1, 7, 3))])
+def test_product_map_form_of_the_last_two_layers(cae, cfgkw, shape, monkeypatch, precision):
+    """Codec decode path (uint8 and float without bridges): the second-to-last layer stores the product of its output
+    with the last layer's weights and the last layer is a gather (cae_kernels_f16.hpp, pmap; f16x3, k = 3).  Against
+    the oracle's truncated reconstruction (<= 1 level, rarely) and against the two-kernel form of the same library;
+    channel counts that do not fill their 32-channel tiles (96 -> 4 tiles, 40 -> 2), one image channel, no GDN."""
+    from oracle import cae_oracle as O
+    from cnn_autoencoder_amd import synth
+    cfg = dict(synth.CANONICAL, **cfgkw)
+    state = synth.synthetic_state(cfg, seed=17)
+    model = cae.autoencoder_from_state_dict(state)
+    dec = model['decoder'].module
+    n, lh, lw = shape
+    torch.manual_seed(2)
+    yq = torch.round(torch.randn(n, cfg['channels_bn'], lh, lw) * 3)
+    x_ref, _ = O.synthesis_forward(yq, oracle_layers(state, 'decoder'))
+    ref8 = (x_ref * 255.0).clip(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+    u8 = dec.forward_u8(yq.cuda()).cpu()
+    d = (u8.int() - ref8.int()).abs()
+    assert u8.shape == ref8.shape and int(d.max()) <= 1 and float((d > 0).float().mean()) < 5e-3
+    xr, _ = dec(yq.cuda(), bridges=False)  # float output through the same form
+    np.testing.assert_allclose(xr[0].cpu().numpy(), x_ref.numpy(), rtol=RTOL, atol=ATOL * max(1.0, float(x_ref.abs().max())))
+    monkeypatch.setenv('CAE_NO_PMAP', '1')  # the two-kernel form
+    u8b = dec.forward_u8(yq.cuda()).cpu()
+    monkeypatch.delenv('CAE_NO_PMAP')
+    d2 = (u8.int() - u8b.int()).abs()
+    assert int(d2.max()) <= 1 and float((d2 > 0).float().mean()) < 5e-3
