@@ -100,7 +100,8 @@ class SlideCoder:
         # SPLIT between them -- decoding costs about twice as much per symbol (2.1 vs 1.1 ns on a Zen 5 core), so it
         # gets the larger share.  Exceeding a cgroup quota throttles the whole process, GPU feeder included.
         self.encode_threads, self.decode_threads = self._split_budget(coder_threads)
-        self.depth = 3  # batches the analysis runs ahead of the synthesis in run()
+        import os
+        self.depth = int(os.environ.get('CAE_PIPELINE_DEPTH', '3'))  # batches the analysis runs ahead of the synthesis in run()
         self._pinned = {}
         self._busy = {}  # pinned buffer key -> event of the asynchronous copy that is still reading it
         self._copy_stream = None  # side stream of the H2D copies
@@ -354,7 +355,7 @@ class SlideCoder:
         # analysis runs DEPTH batches ahead of synthesis: the host always has a batch to code, and the GPU has analysis
         # work while the first batch crosses the host (D2H + encode + decode + H2D ~ 1.8 steps)
         DEPTH = self.depth
-        tm = dict(host_encode=0.0, host_decode=0.0, wait_host=0.0)
+        tm = dict(host_encode=0.0, host_decode=0.0, wait_host=0.0, d2h_copy=0.0)
         all_payloads, stats_parts = [], []
         # all pinned symbol buffers up front (hipHostMalloc of 100 MB costs ~10 ms: not inside the pipeline)
         n0, h0, w0, _ = batches[0].shape
@@ -382,7 +383,9 @@ class SlideCoder:
             ready.synchronize()
             if guard.overflowed():  # f16x3 range guard: repeat this batch on the fp32 kernels
                 sym = self._redo_analysis(batches[k], main)
+            t0 = time.perf_counter()
             _lib.check(_lib.lib().cae_copy_to_host(pin.data_ptr(), sym.data_ptr(), sym.numel() * 4))
+            tm['d2h_copy'] += time.perf_counter() - t0
             return k, pin, hw
 
         def host_encode(pull_future):
@@ -417,8 +420,21 @@ class SlideCoder:
                       else [len(p) + 16 for p in payloads])
             return sse, nbytes, h * w * c, guard, (k, payloads)
 
-        pending = []  # (sse tensor on GPU, nbytes list, samples)
-        # two host workers: batch k+1 is range-encoded while batch k is decoded
+        pending = []  # (sse tensor on GPU, nbytes list, samples, range guard, (k, payloads))
+
+        def finalize(entry):
+            """statistics of a finished batch (its range check needs its kernels done: sse.cpu() synchronises with them);
+            done with a lag of two batches inside the loop, so the payload buffers are released as the run proceeds --
+            released all at once after the loop they cost ~2 ms per batch of pure host time inside the timed region"""
+            sse, nbytes, samples, guard, (k, payloads) = entry
+            sse_host = sse.cpu().tolist()
+            if guard.overflowed():  # f16x3 range guard: repeat this batch's synthesis on the fp32 kernels
+                t = batches[k]
+                rec = self._redo_synthesis(payloads, t.shape[1], t.shape[2], main)
+                sse_host = self.tile_sse(rec, t).cpu().tolist()
+            stats_parts.append(tile_stats(nbytes, sse_host, samples))
+
+        # three host workers: batch k+2 is pulled while batch k+1 is range-encoded and batch k is decoded
         with ThreadPoolExecutor(max_workers=1) as pull_pool, ThreadPoolExecutor(max_workers=1) as enc_pool, \
                 ThreadPoolExecutor(max_workers=1) as dec_pool:
             futs = {}
@@ -439,12 +455,10 @@ class SlideCoder:
                 pending.append(stage_d(k, payloads, back))
                 if keep_payloads:
                     all_payloads.append(payloads)
-        for sse, nbytes, samples, guard, (k, payloads) in pending:
-            sse_host = sse.cpu().tolist()  # (synchronises with the batch's kernels)
-            if guard.overflowed():  # f16x3 range guard: repeat this batch's synthesis on the fp32 kernels
-                t = batches[k]
-                rec = self._redo_synthesis(payloads, t.shape[1], t.shape[2], main)
-                sse_host = self.tile_sse(rec, t).cpu().tolist()
-            stats_parts.append(tile_stats(nbytes, sse_host, samples))
+                del payloads
+                if len(pending) > 2:
+                    finalize(pending.pop(0))
+        while pending:
+            finalize(pending.pop(0))
         self.timers = tm
         return torch.cat(stats_parts), all_payloads
