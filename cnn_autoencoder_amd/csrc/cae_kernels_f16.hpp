@@ -432,6 +432,8 @@ __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gb
             }
 #pragma unroll
             for (int co = 0; co < CT; ++co) {
+                // (at most two fragment pairs in flight: with all CT hoisted the 256-register kernels spilled)
+                if (co == 2) __builtin_amdgcn_sched_barrier(0);
                 const f16x8 gh = *(const f16x8 *)(gb + ((co * 2 + s) * 2 + 0) * 1024);
                 const f16x8 gl = *(const f16x8 *)(gb + ((co * 2 + s) * 2 + 1) * 1024);
                 nrm[co] = mfma3(gh, gl, sh, sl, nrm[co]);
@@ -792,13 +794,26 @@ struct DeconvGeomF16 {
     static constexpr int CONV_STAGE = W_BYTES + HALO_INSTR * 1024;
     static constexpr int STAGE_BYTES = CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES;
     static constexpr int MAXP = (HALO_INSTR + NW - 1) / NW;
+    // IGDN with the WHOLE packed gamma resident in LDS (loaded once per block) when it fits beside the two stage buffers:
+    // the streamed form re-fetched gamma for every (px, row) tile -- 8 passes per block, each of CT stages with a barrier,
+    // a vmcnt wait and only 24 MFMAs per wave to hide them behind.
+    static constexpr int G_ALL = IGDN ? CT * CT * 4096 : 0;
+    static constexpr bool RESIDENT = IGDN && 2 * STAGE_BYTES + G_ALL <= 160 * 1024;
+    static constexpr int PMAP_LDS = NW * 4096;  // OUT_PMAP: one 4-KiB transpose buffer per wave
+    // ... which live behind everything else, or -- when that exceeds the LDS -- in the stage buffer the K loop has
+    // just finished with (one block barrier before the epilogue)
+    static constexpr bool TBUF_IN_STAGE = RESIDENT && 2 * STAGE_BYTES + G_ALL + PMAP_LDS > 160 * 1024;
+    static_assert(!TBUF_IN_STAGE || STAGE_BYTES >= PMAP_LDS, "transpose buffers must fit a stage buffer");
+    static constexpr int lds_bytes(bool pmap) {
+        return 2 * STAGE_BYTES + (RESIDENT ? G_ALL : 0) + ((pmap && !TBUF_IN_STAGE) ? PMAP_LDS : 0);
+    }
     static constexpr int dmin(int py) { return -((py + P) / 2); }
     static constexpr int nky(int py) { return (KS - 1 - py - P) / 2 - dmin(py) + 1; }
 };
 
 template <int KS, int CT, int NW, int PT, bool IGDN, int PY>
 __device__ __forceinline__ void deconv_issue_f16(const LayerArgs &p, const char *in_n, size_t plane_bytes, int s,
-                                                 char *buf, const int *hrow, const long *hbase, int wave, int lane) {
+                                                 char *buf, const int *hrow, const int *hbase, int wave, int lane) {
     using G = DeconvGeomF16<KS, CT, NW, PT, IGDN>;
     constexpr int NKY = G::nky(PY);
     const int q = s / NKY, d = G::dmin(PY) + (s - q * NKY);
@@ -824,9 +839,8 @@ __device__ __forceinline__ void deconv_issue_f16(const LayerArgs &p, const char 
 
 template <int KS, int CT, int NW, int PT, bool IGDN, int PY>
 __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char *in_n, size_t plane_bytes, char *smem,
-                                                 int &sc, const int *hrow, const long *hbase, int wave, int lane,
-                                                 const int (&b_off)[KS], const int (&b_hl)[KS], const int (&b_pt)[KS],
-                                                 int n, int iy, int ix) {
+                                                 int &sc, const int *hrow, const int *hbase, int wave, int lane,
+                                                 const int (&b_off)[KS], int stray_mask, int n, int iy, int ix) {
     using G = DeconvGeomF16<KS, CT, NW, PT, IGDN>;
     constexpr int P = G::P;
     constexpr int STAGE_BYTES = G::STAGE_BYTES;
@@ -846,7 +860,7 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
 #ifndef CAE_EXP_F16_NODMA  // timing-only ablation: no LDS-DMA after the first stage (wrong results)
         if (s + 1 < NS) {
             deconv_issue_f16<KS, CT, NW, PT, IGDN, PY>(p, in_n, plane_bytes, s + 1, nxt, hrow, hbase, wave, lane);
-        } else if (IGDN) {
+        } else if (IGDN && !G::RESIDENT) {
             issue_gamma0<CT, NW>(p, nxt, wave, lane);
         } else if (PY == 0) {
             deconv_issue_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, 0, nxt, hrow, hbase, wave, lane);
@@ -858,10 +872,13 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
             if (PT > 1) __builtin_amdgcn_sched_barrier(0);  // bound operand live ranges to one tap (register budget)
             const int px = (kx + P) & 1;
             f16x8 bh[PT], bl[PT];
+            // (hi -> lo and row -> row strides of the aligned image or of a stray column's, per lane and tap)
+            const bool stray = (stray_mask >> kx) & 1;
+            const int b_hl = stray ? G::ROWS * 16 : G::ROWS * 32 * 16, b_pt = stray ? 16 : 32 * 16;
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
-                bh[pt] = *(const f16x8 *)(cur + b_off[kx] + pt * b_pt[kx]);
-                bl[pt] = *(const f16x8 *)(cur + b_off[kx] + pt * b_pt[kx] + b_hl[kx]);
+                bh[pt] = *(const f16x8 *)(cur + b_off[kx] + pt * b_pt);
+                bl[pt] = *(const f16x8 *)(cur + b_off[kx] + pt * b_pt + b_hl);
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
@@ -884,18 +901,29 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
         ++sc;
     }
 
-    auto store_px = [&](int x) {
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            if (p.outfmt == OUT_PMAP)
-                store_pmap_f16<CT>(acc[x][pt], p, smem + 2 * STAGE_BYTES + wave * 4096, n, 2 * (iy + pt) + PY, x,
-                                   ix - (lane & 31), lane, (iy + pt) < p.H);
-            else
-                store_tiles_f16<CT, true>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h,
-                                          (iy + pt) < p.H && ix < p.W);
-        }
+    // transpose buffer of this wave for the product-map store
+    char *tbuf = smem + 2 * STAGE_BYTES + (G::RESIDENT ? G::G_ALL : 0) + wave * 4096;
+    if constexpr (G::TBUF_IN_STAGE) {
+        __syncthreads();  // every wave is done with the last stage's buffer (sc was incremented past it)
+        tbuf = smem + ((sc + 1) & 1) * STAGE_BYTES + wave * 4096;
+    }
+    auto store = [&](auto x_tag, auto pt_tag) {
+        constexpr int x = decltype(x_tag)::value, pt = decltype(pt_tag)::value;
+        if (p.outfmt == OUT_PMAP)
+            store_pmap_f16<CT>(acc[x][pt], p, tbuf, n, 2 * (iy + pt) + PY, x, ix - (lane & 31), lane, (iy + pt) < p.H);
+        else
+            store_tiles_f16<CT, true>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h, (iy + pt) < p.H && ix < p.W);
     };
-    if constexpr (IGDN) {
+    if constexpr (IGDN && G::RESIDENT) {
+        // gamma resident: no staging, no barriers; one (px, row tile) at a time (64 norm accumulators live)
+        const char *gbuf = smem + 2 * STAGE_BYTES;
+        static_for<2 * PT>([&](auto it) {
+            constexpr int idx = decltype(it)::value;
+            constexpr int x = idx / PT, pt = idx % PT;
+            gdn_resident_f16<CT, true>(acc[x][pt], gbuf, p.beta, lane);
+            store(std::integral_constant<int, x>{}, std::integral_constant<int, pt>{});
+        });
+    } else if constexpr (IGDN) {
         // one (px, row tile) at a time: 64 norm accumulators live instead of 128 (register budget);
         // gamma is re-streamed per tile (L2-resident, 64 KiB)
         static_for<2 * PT>([&](auto it) {
@@ -908,16 +936,13 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
                     deconv_issue_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, 0, nxt, hrow, hbase, wave, lane);
                 }
             });
-            if (p.outfmt == OUT_PMAP)
-                store_pmap_f16<CT>(acc[x][pt], p, smem + 2 * STAGE_BYTES + wave * 4096, n, 2 * (iy + pt) + PY, x,
-                                   ix - (lane & 31), lane, (iy + pt) < p.H);
-            else
-                store_tiles_f16<CT, true>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h,
-                                          (iy + pt) < p.H && ix < p.W);
+            store(std::integral_constant<int, x>{}, std::integral_constant<int, pt>{});
         });
     } else {
-        store_px(0);
-        store_px(1);
+        static_for<2 * PT>([&](auto it) {
+            constexpr int idx = decltype(it)::value;
+            store(std::integral_constant<int, idx / PT>{}, std::integral_constant<int, idx % PT>{});
+        });
     }
 }
 
@@ -937,7 +962,7 @@ __global__ void __launch_bounds__(NW * 64, NW * PT <= 4 ? 2 : 1) deconv_s2_f16_k
     const int iy0 = ty * G::ROWS, ix0 = tx * 32;
 
     int hrow[G::MAXP];
-    long hbase[G::MAXP];  // byte offset of (plane-in-chunk, half, column) inside the chunk, < 0: outside
+    int hbase[G::MAXP];  // byte offset of (plane-in-chunk, half, column) inside the chunk (< 2^31: two planes), < 0: outside
 #pragma unroll
     for (int i = 0; i < G::MAXP; ++i) {
         const int j = wave + i * NW;
@@ -956,36 +981,37 @@ __global__ void __launch_bounds__(NW * 64, NW * PT <= 4 ? 2 : 1) deconv_s2_f16_k
         }
         const int ix = ix0 + c - G::DHI;
         hrow[i] = iy0 + r;
-        hbase[i] = (ix >= 0 && ix < p.W) ? (long)(plhl >> 1) * (long)((size_t)p.H * c8s_row_bytes<true>(p.W)) +
-                                               (long)c8s_piece<true>(ix) + (plhl & 1) * 512
+        hbase[i] = (ix >= 0 && ix < p.W) ? (int)((plhl >> 1) * (int)((size_t)p.H * c8s_row_bytes<true>(p.W)) +
+                                                 (int)c8s_piece<true>(ix) + (plhl & 1) * 512)
                                          : -1;
     }
     const size_t plane_bytes = (size_t)p.H * c8s_row_bytes<true>(p.W);  // input rows are C8SP
     const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
     // B operand of tap kx: plane h, halo row PT*wave + pt, halo column m + DHI - dx(kx): aligned image or a stray's
-    int b_off[KS], b_hl[KS], b_pt[KS];
+    int b_off[KS], stray_mask = 0;
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
         const int pxk = (kx + G::P) & 1, dx = (kx - G::P - pxk) / 2;
         const int c = m + G::DHI - dx, row = PT * wave;
         if (c >= G::DHI && c < G::DHI + 32) {
             b_off[kx] = G::W_BYTES + (((2 * h) * G::ROWS + row) * 32 + c - G::DHI) * 16;
-            b_hl[kx] = G::ROWS * 32 * 16;
-            b_pt[kx] = 32 * 16;
         } else {
             const int js = c < G::DHI ? c : c - 32;
             b_off[kx] = G::W_BYTES + G::AL_BYTES + ((js * 4 + 2 * h) * G::ROWS + row) * 16;
-            b_hl[kx] = G::ROWS * 16;
-            b_pt[kx] = 16;
+            stray_mask |= 1 << kx;
         }
     }
     const int iy = iy0 + PT * wave, ix = ix0 + m;
     int sc = 0;
+    if constexpr (G::RESIDENT) {  // the whole packed gamma, once (landed long before the first epilogue: every stage waits vmcnt 0)
+        for (int j = wave; j < G::G_ALL / 1024; j += NW)
+            glds16((const char *)p.gp + (size_t)j * 1024 + lane * 16, smem + 2 * G::STAGE_BYTES + j * 1024);
+    }
     deconv_issue_f16<KS, CT, NW, PT, IGDN, 0>(p, in_n, plane_bytes, 0, smem, hrow, hbase, wave, lane);
-    deconv_phase_f16<KS, CT, NW, PT, IGDN, 0>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, b_hl, b_pt,
-                                              n, iy, ix);
-    deconv_phase_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, b_hl, b_pt,
-                                              n, iy, ix);
+    deconv_phase_f16<KS, CT, NW, PT, IGDN, 0>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, stray_mask, n,
+                                              iy, ix);
+    deconv_phase_f16<KS, CT, NW, PT, IGDN, 1>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, stray_mask, n,
+                                              iy, ix);
 }
 
 // =================================================================================================

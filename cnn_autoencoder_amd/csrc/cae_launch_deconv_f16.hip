@@ -14,16 +14,15 @@ static int launch_deconv_f16_t(const LayerArgs &a, hipStream_t st) {
 #endif
     constexpr int NW = CAE_DF16_NW, PT = 1;
     using G = DeconvGeomF16<KS, CT, NW, PT, GDN>;
-    constexpr int LDS = 2 * G::STAGE_BYTES;
-    constexpr int PMAP_LDS = NW * 4096;  // OUT_PMAP: one 4-KiB transpose buffer per wave behind the stage buffers
-    if constexpr (LDS > 160 * 1024) {
+    constexpr int LDS = G::lds_bytes(false);
+    if constexpr (2 * G::STAGE_BYTES > 160 * 1024) {
         return fail(CAE_ERR_UNSUPPORTED, "f16x3: this kernel_size/channel combination exceeds the LDS; use fp32");
     } else {
         auto kern = deconv_s2_f16_kernel<KS, CT, NW, PT, GDN>;
         const bool pmap = a.outfmt == OUT_PMAP;
-        if (pmap && LDS + PMAP_LDS > 160 * 1024) return fail(CAE_ERR_UNSUPPORTED, "product map: LDS exceeded");
+        const int lds = pmap ? G::lds_bytes(true) : LDS;
+        if (lds > 160 * 1024) return fail(CAE_ERR_UNSUPPORTED, "product map: LDS exceeded");
         static int attr_bytes = 0;
-        const int lds = LDS + (pmap ? PMAP_LDS : 0);
         if (lds > attr_bytes) {
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             attr_bytes = lds;
