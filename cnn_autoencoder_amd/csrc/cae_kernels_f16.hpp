@@ -236,18 +236,13 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
     constexpr int PAD = KS / 2;
     constexpr int TX = 16, TY = 16;
     constexpr int WH = 2 * TX + KS - 2;
-    // LDS image of a stage's halo.  The tile's input columns are 2 ox0 - PAD .. 2 ox0 + 32 + (PAD - 1): the 32 columns
-    // from 2 ox0 on are one ALIGNED 32-pixel group of the C8S rows (512 contiguous bytes per plane, half and row), the
-    // other KS - 2 are strays to its left and right.  With all WH columns in one row-major image every LDS-DMA
-    // instruction straddled row ends and touched 10-12 partly used cache lines (profiles/r01_experiments.md: 28 cycles
-    // per staged halo KiB against 9 for the contiguous weights).  Now the aligned columns form their own image
-    // [pl][hl][row][32] -- one instruction = two whole 512-byte runs = 8 full lines -- and each stray column is one
-    // instruction of its own ([pl][hl][row], 64 pieces).
-    constexpr int NSTRAY = WH - 32;                // = KS - 2: PAD to the left, PAD - 1 to the right
-    constexpr int AL_INSTR = 4 * TY * 32 / 64;     // aligned part
-    constexpr int AL_BYTES = AL_INSTR * 1024;
-    constexpr int HALO_INSTR = AL_INSTR + NSTRAY;  // (4 * TY = 64 pieces per stray column)
-    static_assert(TY == 16 && TX == 16, "the halo image assumes 16 x 16 tiles");
+    // (Round 2 tried an "aligned" halo image -- the 32 columns that coincide with one 32-pixel group of the C8S rows as
+    //  whole 512-byte runs, the KS - 2 stray columns apart: no gain (profiles/r02_experiments.md 4), and its 512-byte row
+    //  pitch made the stride-2 operand reads 2-way bank conflicted (1.4 conflict cycles per LDS-active cycle); the
+    //  33-piece pitch of this row-major image is conflict-free.  deconv_s2_f16, whose reads are contiguous, keeps it.)
+    constexpr int PLANE_PIECES = TY * WH;          // 16-byte pieces per (plane, half)
+    constexpr int HALO_PIECES = 4 * PLANE_PIECES;  // [pl][hl][row][x]
+    constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;
     constexpr int W_INSTR = KS * CT * 2;
     constexpr int W_BYTES = W_INSTR * 1024;
     constexpr int G_BYTES = GDN ? CT * 4096 : 0;
@@ -272,21 +267,13 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
     unsigned hoff[MAXP][KS];
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-        const int j = wave + i * NW;
-        int plhl, r, c;  // (plane, half), halo row, halo column of this lane's piece in instruction j
-        if (j < AL_INSTR) {
-            const int pc = j * 64 + lane;
-            plhl = pc >> 9;
-            r = (pc >> 5) & 15;
-            c = PAD + (pc & 31);
-        } else {
-            const int js = j - AL_INSTR < NSTRAY ? j - AL_INSTR : NSTRAY - 1;
-            plhl = lane >> 4;
-            r = lane & 15;
-            c = js < PAD ? js : 32 + js;
-        }
+        int pc = (wave + i * NW) * 64 + lane;
+        pc = pc < HALO_PIECES ? pc : HALO_PIECES - 1;
+        const int plhl = pc / PLANE_PIECES;
+        const int rem = pc - plhl * PLANE_PIECES;
+        const int r = rem / WH, x = rem - r * WH;
         const unsigned base = (unsigned)(plhl >> 1) * (unsigned)plane_bytes + (unsigned)(plhl & 1) * 512u +
-                              c8s_piece<false>(reflect_idx(2 * ox0 - PAD + c, p.W));
+                              c8s_piece<false>(reflect_idx(2 * ox0 - PAD + x, p.W));
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
             hoff[i][ky] = base + (unsigned)reflect_idx(2 * (oy0 + r) - PAD + ky, p.H) *
@@ -320,23 +307,10 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) init_acc<CT>(acc[pt], p.bias, h, 0.0f);
 
-    // B operand of (column tile pt, tap kx): plane h, halo row 2 PT w + 2 pt + (m>>4), halo column 2(m&15) + kx --
-    // in the aligned image or in a stray column's, decided per lane and tap
-    int b_off[KS], b_hl[KS], b_pt[KS];  // byte offset (hi half, column tile 0), hi -> lo, column tile 0 -> 1
-#pragma unroll
-    for (int kx = 0; kx < KS; ++kx) {
-        const int c = 2 * (m & 15) + kx, row = 2 * PT * wave + (m >> 4);
-        if (c >= PAD && c < PAD + 32) {
-            b_off[kx] = W_BYTES + (((2 * h) * TY + row) * 32 + c - PAD) * 16;
-            b_hl[kx] = TY * 32 * 16;
-            b_pt[kx] = 2 * 32 * 16;
-        } else {
-            const int js = c < PAD ? c : c - 32;
-            b_off[kx] = W_BYTES + AL_BYTES + ((js * 4 + 2 * h) * TY + row) * 16;
-            b_hl[kx] = TY * 16;
-            b_pt[kx] = 2 * 16;
-        }
-    }
+    // B operand of (column tile pt, tap kx): halo [pl = h][hl][row 4w + 2pt + (m>>4)][2(m&15) + kx]
+    const int b_off = W_BYTES + (((2 * h) * TY + 2 * PT * wave + (m >> 4)) * WH + 2 * (m & 15)) * 16;
+    constexpr int B_HL = PLANE_PIECES * 16;  // hi -> lo
+    constexpr int B_PT = 2 * WH * 16;        // column tile 0 -> 1 (two rows down)
     int sc = 0;
 
     issue_stage(0, std::integral_constant<int, 0>{}, smem);
@@ -363,6 +337,7 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
             }
 #endif
             const char *wb = cur + lane * 16;
+            const char *hb = cur + b_off;
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
 #ifdef CAE_EXP_F16C_ONETAP
@@ -373,8 +348,8 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
                 f16x8 bh[PT], bl[PT];
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) {
-                    bh[pt] = *(const f16x8 *)(cur + b_off[kxr] + pt * b_pt[kxr]);
-                    bl[pt] = *(const f16x8 *)(cur + b_off[kxr] + pt * b_pt[kxr] + b_hl[kxr]);
+                    bh[pt] = *(const f16x8 *)(hb + pt * B_PT + kxr * 16);
+                    bl[pt] = *(const f16x8 *)(hb + pt * B_PT + kxr * 16 + B_HL);
                 }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {

@@ -179,7 +179,7 @@ int launch_wg_t(const WGArgs &a, size_t lds, int ksplit, int at, int tg, hipStre
 template <int CT, int MODE>
 int launch_gdn_a_t(const GdnArgs &a, hipStream_t st) {
     auto kern = gdn_gemm_a_kernel<CT, MODE>;
-    constexpr int LDS = CT * 32 * (CT * 32 + 4) * 4;
+    constexpr int LDS = CT * 32 * (CT * 32 + 4) * 4 + (CT <= 4 ? 2 * 32768 : 0);  // M (+ the A double buffer)
     static bool done = false;
     if (!done) {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));

@@ -406,11 +406,20 @@ struct GdnArgs {
     int C, inverse;
 };
 
+// A operand staging (CT <= 4: LDS has room beside M): per 32-channel chunk the block's 256 x 32 fp32 tile is copied by
+// LDS-DMA as whole 128-byte row segments (8 pixels per instruction) into a dense, XOR-swizzled image -- slot of piece s
+// of pixel p = 8 p + (s ^ ((p >> 1) & 7)) -- which the MFMA lanes (one pixel each, stride 128 B) then read without bank
+// conflicts; double-buffered under the 128 MFMAs a wave issues per chunk.  Reading A straight from HBM (16 bytes per
+// lane and pixel row, 32 lines per instruction, the tile thrashing the 32-KiB L1) made these kernels 12x slower than
+// their MFMA time (profiles/r02_experiments.md 8); that form remains for CT > 4, where M alone fills the LDS.
 template <int CT, int MODE>
 __global__ void __launch_bounds__(256, 1) gdn_gemm_a_kernel(const GdnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int C = CT * 32, LD = C + 4;
+    constexpr bool STAGED = CT <= 4;
+    constexpr int M_BYTES = C * LD * 4;
     float *mlds = (float *)smem;
+    char *abuf = smem + M_BYTES;  // STAGED: 2 x 32 KiB
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, m = lane & 31;
@@ -433,27 +442,74 @@ __global__ void __launch_bounds__(256, 1) gdn_gemm_a_kernel(const GdnArgs p) {
                 acc[1][ct][r] = b;
             }
         }
-        long pa0 = p0 + m, pa1 = p0 + 32 + m;
-        pa0 = pa0 < p.pixels ? pa0 : p.pixels - 1;  // clamped rows are computed and never stored
-        pa1 = pa1 < p.pixels ? pa1 : p.pixels - 1;
-        const float *a0 = p.a + pa0 * C + 4 * h, *a1 = p.a + pa1 * C + 4 * h;
-#pragma unroll 2
-        for (int q = 0; q < C / 8; ++q) {
-            f32x4 v0 = *(const f32x4 *)(a0 + 8 * q), v1 = *(const f32x4 *)(a1 + 8 * q);
-            if (MODE != 2) {
-                v0 *= v0;
-                v1 *= v1;
+        if constexpr (STAGED) {
+            // this thread's 8 pieces of a chunk: instruction j = wave + 4 i covers pixels 8j .. 8j+7 of the tile
+            const char *src[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = wave + 4 * i;
+                const int px = 8 * j + (lane >> 3);
+                long gp = tile * 256 + px;
+                gp = gp < p.pixels ? gp : p.pixels - 1;  // clamped rows are computed and never stored
+                const int s = (lane & 7) ^ ((px >> 1) & 7);
+                src[i] = (const char *)(p.a + gp * C) + s * 16;
             }
-            f32x4 mf[CT];
+            auto issue = [&](int chunk, char *buf) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) mf[ct] = *(const f32x4 *)(mlds + (32 * ct + m) * LD + 8 * q + 4 * h);
+                for (int i = 0; i < 8; ++i) glds16(src[i] + chunk * 128, buf + (wave + 4 * i) * 1024);
+            };
+            __syncthreads();  // the previous tile's reads of both buffers are done
+            issue(0, abuf);
+            const int pl0 = 64 * wave + m, pl1 = pl0 + 32;
+            for (int chunk = 0; chunk < CT; ++chunk) {
+                wait_vm0();
+                __syncthreads();
+                char *cur = abuf + (chunk & 1) * 32768;
+                if (chunk + 1 < CT) issue(chunk + 1, abuf + ((chunk + 1) & 1) * 32768);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v0 = *(const f32x4 *)(cur + (pl0 * 8 + ((2 * q + h) ^ ((pl0 >> 1) & 7))) * 16);
+                    f32x4 v1 = *(const f32x4 *)(cur + (pl1 * 8 + ((2 * q + h) ^ ((pl1 >> 1) & 7))) * 16);
+                    if (MODE != 2) {
+                        v0 *= v0;
+                        v1 *= v1;
+                    }
+                    f32x4 mf[CT];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[s], mf[ct][s], acc[0][ct], 0, 0, 0);
-                    acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[s], mf[ct][s], acc[1][ct], 0, 0, 0);
+                    for (int ct = 0; ct < CT; ++ct)
+                        mf[ct] = *(const f32x4 *)(mlds + (32 * ct + m) * LD + 32 * chunk + 8 * q + 4 * h);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) {
+                            acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[s], mf[ct][s], acc[0][ct], 0, 0, 0);
+                            acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[s], mf[ct][s], acc[1][ct], 0, 0, 0);
+                        }
                 }
+            }
+        } else {
+            long pa0 = p0 + m, pa1 = p0 + 32 + m;
+            pa0 = pa0 < p.pixels ? pa0 : p.pixels - 1;  // clamped rows are computed and never stored
+            pa1 = pa1 < p.pixels ? pa1 : p.pixels - 1;
+            const float *a0 = p.a + pa0 * C + 4 * h, *a1 = p.a + pa1 * C + 4 * h;
+#pragma unroll 2
+            for (int q = 0; q < C / 8; ++q) {
+                f32x4 v0 = *(const f32x4 *)(a0 + 8 * q), v1 = *(const f32x4 *)(a1 + 8 * q);
+                if (MODE != 2) {
+                    v0 *= v0;
+                    v1 *= v1;
+                }
+                f32x4 mf[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) mf[ct] = *(const f32x4 *)(mlds + (32 * ct + m) * LD + 8 * q + 4 * h);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[s], mf[ct][s], acc[0][ct], 0, 0, 0);
+                        acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[s], mf[ct][s], acc[1][ct], 0, 0, 0);
+                    }
+            }
         }
         static_for<2>([&](auto pt_tag) {
             constexpr int pt = decltype(pt_tag)::value;

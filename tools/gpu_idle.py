@@ -9,7 +9,8 @@ kt = glob.glob(os.path.join(sys.argv[1], '**', '*kernel_trace.csv'), recursive=T
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(kt))]
 rows.sort()
 # steady state = between the 25 % and 75 % occurrences of the last synthesis kernel (bench's timed loop dominates)
-marks = [r for r in rows if 'deconv_last' in r[2]] or rows
+marks = ([r for r in rows if 'deconv_last' in r[2]] or [r for r in rows if 'pmap_gather' in r[2]] or
+         [r for r in rows if 'conv_first' in r[2]] or rows)
 lo, hi = marks[len(marks) // 4][0], marks[(3 * len(marks)) // 4][1]
 mid = [r for r in rows if r[0] >= lo and r[1] <= hi]
 busy, cur_s, cur_e, gaps = 0, None, None, []

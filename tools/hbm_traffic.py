@@ -27,7 +27,7 @@ fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
 write = per_kernel(sys.argv[2], 'WRITE_SIZE')
 out = {}
 for k in fetch:
-    if not any(t in k for t in ('conv', 'quantize', 'nchw', 'tile_sse', 'u64', 'likelihood')):
+    if not any(t in k for t in ('conv', 'quantize', 'nchw', 'tile_sse', 'u64', 'likelihood', 'pmap')):
         continue
     fx2 = 2 * fetch[k] * 1024 / 1e6
     w = write.get(k, 0.0) * 1024 / 1e6
