@@ -354,6 +354,7 @@ int cae_t_gdn_backward(const float *z32, const float *gext32, int n, int h, int 
     if (n < 1 || h < 1 || w < 1 || pad < 0 || bad_channels(cp)) return fail(CAE_ERR_ARG, "bad shape");
     hipStream_t st = (hipStream_t)stream;
     const long pixels = (long)n * h * w;
+    if (pixels >= (1l << 31)) return fail(CAE_ERR_ARG, "more than 2^31 pixels per call");
     GdnArgs a{};
     a.a = z32;
     a.mat = gamma;

@@ -517,30 +517,43 @@ __global__ void __launch_bounds__(256, 1) gdn_gemm_a_kernel(const GdnArgs p) {
                 constexpr int r = decltype(r_tag)::value;
                 const long pix = p0 + 32 * pt + acc_row(r) + 4 * h;
                 if (pix < p.pixels) {
+                    // (n, y, x) of the pixel once per accumulator row, in 32-bit arithmetic: the 64-bit divisions of the
+                    // first version, repeated per channel tile, were most of the backward kernel's time
+                    int nimg = 0, py = 0, px = 0;
+                    bool interior = true;
+                    if (MODE == 1) {
+                        const unsigned hw = (unsigned)(p.img_h * p.img_w), upix = (unsigned)pix;
+                        nimg = (int)(upix / hw);
+                        const unsigned rem = upix - (unsigned)nimg * hw;
+                        py = (int)(rem / (unsigned)p.img_w);
+                        px = (int)(rem - (unsigned)py * (unsigned)p.img_w);
+                        const int P = p.gy.P;
+                        interior = P == 0 || (py > P && py < p.img_h - 1 - P && px > P && px < p.img_w - 1 - P);
+                    }
+                    const size_t gbase = MODE == 1 ? (((size_t)nimg * (p.img_h + 2 * p.gy.P) + py + p.gy.P) *
+                                                          (p.img_w + 2 * p.gy.P) + px + p.gy.P) * C
+                                                   : 0;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
                         const int c = 32 * ct + m;
                         const size_t off = (size_t)pix * C + c;
                         const float d = acc[pt][ct][r];
                         if (MODE == 0) {
-                            const float y = p.z[off] * (p.inverse ? __builtin_sqrtf(d) : 1.0f / __builtin_sqrtf(d));
+                            const float y = p.z[off] * (p.inverse ? __builtin_amdgcn_sqrtf(d) : __builtin_amdgcn_rsqf(d));
                             if (p.o32a) p.o32a[off] = y;
                             if (p.o16) ((__bf16 *)p.o16)[off] = (__bf16)y;
                         } else if (MODE == 1) {
-                            const long hw = (long)p.img_h * p.img_w;
-                            const int nimg = (int)(pix / hw);
-                            const int rem = (int)(pix - nimg * hw);
-                            const float gy = fold_read(p.gy, nimg, rem / p.img_w, rem % p.img_w, C, c);
+                            const float gy = interior ? p.gy.g[gbase + c] : fold_read(p.gy, nimg, py, px, C, c);
                             const float zz = p.z[off];
-                            const float sq = __builtin_sqrtf(d);
                             float gn, gd;
                             if (p.inverse) {
+                                const float sq = __builtin_amdgcn_sqrtf(d);
                                 gd = gy * sq;
-                                gn = 0.5f * gy * zz / sq;
+                                gn = 0.5f * gy * zz * __builtin_amdgcn_rsqf(d);
                             } else {
-                                const float rs = 1.0f / sq;
+                                const float rs = __builtin_amdgcn_rsqf(d);
                                 gd = gy * rs;
-                                gn = -0.5f * gy * zz * rs / d;
+                                gn = -0.5f * gy * zz * rs * rs * rs;
                             }
                             p.o32a[off] = gn;
                             p.o32b[off] = gd;
