@@ -22,6 +22,16 @@
 
 namespace cae {
 
+#ifndef CAE_F16_ISSUERS
+#define CAE_F16_ISSUERS 2  // LDS-DMA issuer waves of conv_s2_f16 / deconv_s2_f16: NI = NW / CAE_F16_ISSUERS
+#endif
+// issuer index of wave w (0 .. NI-1), or -1: the first NI waves, or (CAE_F16_ISSUE_HI) the last NI
+#ifdef CAE_F16_ISSUE_HI
+#define ISSUER(w, NW, NI) ((w) >= (NW) - (NI) ? (w) - ((NW) - (NI)) : -1)
+#else
+#define ISSUER(w, NW, NI) ((w) < (NI) ? (w) : -1)
+#endif
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -248,7 +258,15 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
     constexpr int G_BYTES = GDN ? CT * 4096 : 0;
     constexpr int CONV_STAGE = W_BYTES + HALO_INSTR * 1024;
     constexpr int STAGE_BYTES = CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES;
-    constexpr int MAXP = (HALO_INSTR + NW - 1) / NW;
+    // LDS-DMA issuers: NI waves stage the next stage, the others go straight to their MFMAs.  Waves w and w + NW/2 share
+    // a SIMD: with NI = NW/2 one wave per SIMD spends the first part of a stage issuing the copies (tens of cycles per
+    // instruction) while its partner has the matrix pipe to itself, then computes while the partner waits at the
+    // barrier -- the two waves of a SIMD run half a stage apart instead of in lockstep (profiles/r02_experiments.md 9).
+#ifndef CAE_F16_ISSUERS
+#define CAE_F16_ISSUERS 2  // divisor: NI = NW / CAE_F16_ISSUERS
+#endif
+    constexpr int NI = NW / CAE_F16_ISSUERS > 0 ? NW / CAE_F16_ISSUERS : 1;
+    constexpr int MAXP = (HALO_INSTR + NI - 1) / NI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -267,7 +285,7 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
     unsigned hoff[MAXP][KS];
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-        int pc = (wave + i * NW) * 64 + lane;
+        int pc = (ISSUER(wave, NW, NI) + i * NI) * 64 + lane;
         pc = pc < HALO_PIECES ? pc : HALO_PIECES - 1;
         const int plhl = pc / PLANE_PIECES;
         const int rem = pc - plhl * PLANE_PIECES;
@@ -283,13 +301,15 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
 
     auto issue_stage = [&](int q, auto ky_tag, char *buf) {
         constexpr int ky = decltype(ky_tag)::value;
+        if (ISSUER(wave, NW, NI) < 0) return;
+        const int iw = ISSUER(wave, NW, NI);
         const char *wsrc = (const char *)p.wp + (size_t)(q * KS + ky) * W_BYTES;
 #ifdef CAE_EXP_F16C_NOWDMA  // timing-only ablation: weights staged for stage 0 only (wrong results)
         if (q == 0 && ky == 0)
 #endif
 #pragma unroll
-        for (int i = 0; i < (W_INSTR + NW - 1) / NW; ++i) {
-            const int j = wave + i * NW;
+        for (int i = 0; i < (W_INSTR + NI - 1) / NI; ++i) {
+            const int j = iw + i * NI;
             if (j < W_INSTR) glds16(wsrc + j * 1024 + woff, buf + j * 1024);
         }
         const char *planes = in_n + (size_t)(2 * q) * plane_bytes;
@@ -298,7 +318,7 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
 #endif
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
-            const int j = wave + i * NW;
+            const int j = iw + i * NI;
             if (j < HALO_INSTR) glds16(planes + hoff[i][ky], buf + W_BYTES + j * 1024);
         }
     };
@@ -313,6 +333,9 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
     constexpr int B_PT = 2 * WH * 16;        // column tile 0 -> 1 (two rows down)
     int sc = 0;
 
+#ifdef CAE_EXP_SETPRIO  // static priority for the younger half of the block (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     issue_stage(0, std::integral_constant<int, 0>{}, smem);
     for (int q = 0; q < p.cci; ++q) {
         static_for<KS>([&](auto ky_tag) {
@@ -408,7 +431,7 @@ __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gb
 #pragma unroll
             for (int co = 0; co < CT; ++co) {
                 // (at most two fragment pairs in flight: with all CT hoisted the 256-register kernels spilled)
-                if (co == 2) __builtin_amdgcn_sched_barrier(0);
+                if (co & 1) __builtin_amdgcn_sched_barrier(0);
                 const f16x8 gh = *(const f16x8 *)(gb + ((co * 2 + s) * 2 + 0) * 1024);
                 const f16x8 gl = *(const f16x8 *)(gb + ((co * 2 + s) * 2 + 1) * 1024);
                 nrm[co] = mfma3(gh, gl, sh, sl, nrm[co]);
@@ -768,7 +791,13 @@ struct DeconvGeomF16 {
     static constexpr int G_BYTES = IGDN ? CT * 4096 : 0;
     static constexpr int CONV_STAGE = W_BYTES + HALO_INSTR * 1024;
     static constexpr int STAGE_BYTES = CONV_STAGE > G_BYTES ? CONV_STAGE : G_BYTES;
-    static constexpr int MAXP = (HALO_INSTR + NW - 1) / NW;
+    static constexpr int NI = NW / CAE_F16_ISSUERS > 0 ? NW / CAE_F16_ISSUERS : 1;  // LDS-DMA issuer waves (conv_s2_f16)
+    static constexpr int MAXP = (HALO_INSTR + NI - 1) / NI;
+    // aligned pieces per issuer and their (plane, half) step: piece i of issuer iw is instruction iw + i NI, i.e. halo
+    // piece (iw 64 + lane) + i NI 64 -- the same (row, column), AL_STEP (plane, half) images further
+    static constexpr int AL_PER = AL_INSTR / NI, AL_STEP = NI * 64 / (ROWS * 32);
+    static_assert(AL_INSTR % NI == 0 && (NI * 64) % (ROWS * 32) == 0 && AL_STEP <= 2 && STRAY_INSTR <= NI,
+                  "issuer waves must each cover whole (plane, half) images of the aligned halo");
     // IGDN with the WHOLE packed gamma resident in LDS (loaded once per block) when it fits beside the two stage buffers:
     // the streamed form re-fetched gamma for every (px, row) tile -- 8 passes per block, each of CT stages with a barrier,
     // a vmcnt wait and only 24 MFMAs per wave to hide them behind.
@@ -793,22 +822,34 @@ __device__ __forceinline__ void deconv_issue_f16(const LayerArgs &p, const char 
     constexpr int NKY = G::nky(PY);
     const int q = s / NKY, d = G::dmin(PY) + (s - q * NKY);
     const int ky = 2 * d + PY + G::P;
+    if (ISSUER(wave, NW, G::NI) < 0) return;
+    const int iw = ISSUER(wave, NW, G::NI);
     const char *wsrc = (const char *)p.wp + (size_t)(q * KS + ky) * G::W_BYTES;
 #pragma unroll
-    for (int i = 0; i < (G::W_INSTR + NW - 1) / NW; ++i) {
-        const int j = wave + i * NW;
+    for (int i = 0; i < (G::W_INSTR + G::NI - 1) / G::NI; ++i) {
+        const int j = iw + i * G::NI;
         if (j < G::W_INSTR) glds16(wsrc + j * 1024 + lane * 16, buf + j * 1024);
     }
     const char *planes = in_n + (size_t)(2 * q) * plane_bytes;
+    const size_t row_bytes = c8s_row_bytes<true>(p.W);
+    {
+        // aligned image: the issuer's pieces i = 0 .. AL_PER - 1 are the same (row, column) of consecutive
+        // (plane, half) images, so ONE lane offset + uniform strides address them all (hbase[0], hrow[0])
+        const int iy = hrow[0] - d;
+        const bool ok = iy >= 0 && iy < p.H && hbase[0] >= 0;
+        const char *src = planes + hbase[0] + (size_t)iy * row_bytes;
 #pragma unroll
-    for (int i = 0; i < G::MAXP; ++i) {
-        const int j = wave + i * NW;
-        if (j < G::HALO_INSTR) {
-            const int iy = hrow[i] - d;
-            const bool ok = iy >= 0 && iy < p.H && hbase[i] >= 0;
-            const char *src = ok ? planes + hbase[i] + (size_t)iy * c8s_row_bytes<true>(p.W) : (const char *)p.zero;
-            glds16(src, buf + G::W_BYTES + j * 1024);
+        for (int i = 0; i < G::AL_PER; ++i) {
+            constexpr int K = G::AL_STEP;
+            const char *g = ok ? src + (size_t)((i * K) >> 1) * plane_bytes + ((i * K) & 1) * 512 : (const char *)p.zero;
+            glds16(g, buf + G::W_BYTES + (iw + i * G::NI) * 1024);
         }
+    }
+    if (iw < G::STRAY_INSTR) {  // stray columns: one instruction per issuer (hbase[1], hrow[1])
+        const int iy = hrow[1] - d;
+        const bool ok = iy >= 0 && iy < p.H && hbase[1] >= 0;
+        const char *g = ok ? planes + hbase[1] + (size_t)iy * row_bytes : (const char *)p.zero;
+        glds16(g, buf + G::W_BYTES + (G::AL_INSTR + iw) * 1024);
     }
 }
 
@@ -936,29 +977,24 @@ __global__ void __launch_bounds__(NW * 64, NW * PT <= 4 ? 2 : 1) deconv_s2_f16_k
     const int n = bid / p.tiles_y;
     const int iy0 = ty * G::ROWS, ix0 = tx * 32;
 
-    int hrow[G::MAXP];
-    int hbase[G::MAXP];  // byte offset of (plane-in-chunk, half, column) inside the chunk (< 2^31: two planes), < 0: outside
-#pragma unroll
-    for (int i = 0; i < G::MAXP; ++i) {
-        const int j = wave + i * NW;
-        int plhl, r, c;  // (plane, half), halo row, halo column of this lane's piece in instruction j
-        if (j < G::AL_INSTR) {
-            const int pc = j * 64 + lane;
-            plhl = pc / (G::ROWS * 32);
-            r = (pc / 32) % G::ROWS;
-            c = G::DHI + (pc & 31);
-        } else {
-            int js = (j - G::AL_INSTR) * (64 / (4 * G::ROWS)) + lane / (4 * G::ROWS);
-            js = js < G::NSTRAY ? js : G::NSTRAY - 1;
-            plhl = (lane / G::ROWS) & 3;
-            r = lane % G::ROWS;
-            c = js < G::DHI ? js : 32 + js;
-        }
-        const int ix = ix0 + c - G::DHI;
-        hrow[i] = iy0 + r;
-        hbase[i] = (ix >= 0 && ix < p.W) ? (int)((plhl >> 1) * (int)((size_t)p.H * c8s_row_bytes<true>(p.W)) +
-                                                 (int)c8s_piece<true>(ix) + (plhl & 1) * 512)
-                                         : -1;
+    // LDS-DMA sources of this lane: [0] its piece of the aligned image (first of AL_PER), [1] its stray piece.
+    // hbase = byte offset of (plane-in-chunk, half, column) inside the chunk (< 2^31: two planes), < 0: outside;
+    // hrow = input row of the piece at d = 0
+    int hrow[2], hbase[2];
+    {
+        const int iw = ISSUER(wave, NW, G::NI) < 0 ? 0 : ISSUER(wave, NW, G::NI);
+        const int plane_i = (int)((size_t)p.H * c8s_row_bytes<true>(p.W));
+        const int pc = iw * 64 + lane;
+        int plhl = pc / (G::ROWS * 32);
+        int ixp = ix0 + (pc & 31);
+        hrow[0] = iy0 + (pc / 32) % G::ROWS;
+        hbase[0] = ixp < p.W ? (plhl >> 1) * plane_i + (int)c8s_piece<true>(ixp) + (plhl & 1) * 512 : -1;
+        int js = iw * (64 / (4 * G::ROWS)) + lane / (4 * G::ROWS);
+        js = js < G::NSTRAY ? js : G::NSTRAY - 1;
+        plhl = (lane / G::ROWS) & 3;
+        ixp = ix0 + (js < G::DHI ? js : 32 + js) - G::DHI;
+        hrow[1] = iy0 + lane % G::ROWS;
+        hbase[1] = (ixp >= 0 && ixp < p.W) ? (plhl >> 1) * plane_i + (int)c8s_piece<true>(ixp) + (plhl & 1) * 512 : -1;
     }
     const size_t plane_bytes = (size_t)p.H * c8s_row_bytes<true>(p.W);  // input rows are C8SP
     const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
@@ -982,6 +1018,9 @@ __global__ void __launch_bounds__(NW * 64, NW * PT <= 4 ? 2 : 1) deconv_s2_f16_k
         for (int j = wave; j < G::G_ALL / 1024; j += NW)
             glds16((const char *)p.gp + (size_t)j * 1024 + lane * 16, smem + 2 * G::STAGE_BYTES + j * 1024);
     }
+#ifdef CAE_EXP_SETPRIO
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     deconv_issue_f16<KS, CT, NW, PT, IGDN, 0>(p, in_n, plane_bytes, 0, smem, hrow, hbase, wave, lane);
     deconv_phase_f16<KS, CT, NW, PT, IGDN, 0>(p, in_n, plane_bytes, smem, sc, hrow, hbase, wave, lane, b_off, stray_mask, n,
                                               iy, ix);
