@@ -22,6 +22,9 @@
 
 namespace cae {
 
+#ifndef CAE_F16_PIPE
+#define CAE_F16_PIPE 0  // 1: software-pipelined operand reads in deconv_s2_f16's K loop (measured null: the stack is power-limited)
+#endif
 #ifndef CAE_F16_ISSUERS
 #define CAE_F16_ISSUERS 2  // LDS-DMA issuer waves of conv_s2_f16 / deconv_s2_f16: NI = NW / CAE_F16_ISSUERS
 #endif
@@ -883,6 +886,54 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
         }
 #endif
         const char *wb = cur + lane * 16;
+#if CAE_F16_PIPE
+        if constexpr (PT == 1) {
+            // software-pipelined stage: the operand fragments of group pair g + 1 are read from LDS before the six
+            // MFMAs of pair g are issued (one register set ahead), and the two groups of a pair (two channel tiles of a
+            // tap) alternate so that consecutive MFMAs never depend on each other.  Without this the compiler
+            // re-used ONE fragment register set: read -> lgkmcnt(0) -> 1-2 MFMAs, the LDS latency exposed 24 times
+            // per stage and wave.
+            static_assert(CT % 2 == 0 || CT == 1, "channel tiles are paired");
+            constexpr int GP = CT == 1 ? 1 : 2;          // groups (channel tiles) per step
+            constexpr int NSTEP = KS * CT / GP;
+            f16x8 a[2][GP][2], b[2][2];                  // [set][group][hi, lo], [set][hi, lo]
+            auto load_b = [&](int kx, int set) {
+                const bool stray = (stray_mask >> kx) & 1;
+                const int b_hl = stray ? G::ROWS * 16 : G::ROWS * 32 * 16;
+                b[set][0] = *(const f16x8 *)(cur + b_off[kx]);
+                b[set][1] = *(const f16x8 *)(cur + b_off[kx] + b_hl);
+            };
+            auto load_a = [&](int step, int set) {
+#pragma unroll
+                for (int g = 0; g < GP; ++g) {
+                    a[set][g][0] = *(const f16x8 *)(wb + ((step * GP + g) * 2 + 0) * 1024);
+                    a[set][g][1] = *(const f16x8 *)(wb + ((step * GP + g) * 2 + 1) * 1024);
+                }
+            };
+            load_b(0, 0);
+            load_a(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * GP, 0);
+            static_for<NSTEP>([&](auto it) {
+                constexpr int st = decltype(it)::value;
+                constexpr int kx = st * GP / CT, ct0 = st * GP % CT;
+                constexpr int px = (kx + P) & 1;
+                constexpr bool more = st + 1 < NSTEP, next_tap = more && (st + 1) * GP % CT == 0;
+                constexpr int nread = more ? 2 * GP + (next_tap ? 2 : 0) : 0;
+                if constexpr (more) load_a(st + 1, (st + 1) & 1);
+                if constexpr (next_tap) load_b(kx + 1, (kx + 1) & 1);
+                const f16x8 bh = b[kx & 1][0], bl = b[kx & 1][1];
+                f32x16 *dst = px == 0 ? acc[0][0] : acc[1][0];
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int g = 0; g < GP; ++g)
+                        dst[ct0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[st & 1][g][m == 2], m == 1 ? bl : bh,
+                                                                              dst[ct0 + g], 0, 0, 0);
+                if constexpr (nread > 0) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);  // next step's reads,
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * GP, 0);                         // then this step's MFMAs
+            });
+        } else
+#endif
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
             if (PT > 1) __builtin_amdgcn_sched_barrier(0);  // bound operand live ranges to one tap (register budget)
