@@ -492,7 +492,7 @@ static bool last_f16_fits(int ks, int cin) {
 }
 
 static bool conv_f16_fits(int ks, int ct, bool gdn) {
-    if (gdn && ct > 4) return false;
+    if (gdn && ct > 4) gdn = false;  // wider than 128 channels: convolution without the epilogue + gdn_f16_kernel
     const int halo_instr = (4 * 16 * (2 * 16 + ks - 2) + 63) / 64;
     const int stage = std::max(ks * ct * 2048 + halo_instr * 1024, gdn ? ct * 4096 : 0);
     return 2 * stage <= 160 * 1024;
@@ -855,7 +855,7 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
                 a.wp = l.wp_edge;
                 if ((rc = launch_first(m->ks, l.ct, l.gdn, a, f, st))) return rc;
             }
-        } else if (f16 && conv_f16_fits(m->ks, l.ct, l.gdn)) {
+        } else if (f16 && conv_f16_fits(m->ks, l.ct, l.gdn) && !(l.gdn && l.ct > 4 && last)) {
             a.wp = (const float *)l.wp16;
             a.gp = (const float *)l.gp16;
             a.cci = (l.cin + 15) / 16;

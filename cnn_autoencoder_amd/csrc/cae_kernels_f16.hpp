@@ -183,12 +183,9 @@ __host__ __device__ __forceinline__ unsigned c8s_piece(int x) {
 
 // store CT accumulator tiles of one pixel column-tile: C8S (split halves; SP: C8SP rows) | NCHW fp32 | HWC uint8
 template <int CT, bool SP = false>
-__device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
-                                                int h, bool valid) {
-    // (the half-wave exchange below needs both lanes of a pixel: lanes l and l+32 share (oy, ox),
-    //  hence the same `valid`; invalid pairs skip the whole store)
-    if (!valid) return;
-    if (p.outfmt == OUT_C8) {
+__device__ __forceinline__ void store_split_f16(const f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox, int h,
+                                                int ct0 = 0) {  // acc[ct] = channel tile ct0 + ct
+    {
         // lane (px, h) holds channels 4h..4h+3 of every plane as hi (H) and lo (L) halves.  One
         // v_permlane32_swap per dword leaves the lower lane with [H(ch 0-3) | H(ch 4-7)] and the upper
         // lane with [L(ch 0-3) | L(ch 4-7)]: one 16-byte store per lane and plane instead of two 8-byte.
@@ -204,7 +201,7 @@ __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const L
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int plane = 4 * ct + g;
+                const int plane = 4 * (ct0 + ct) + g;
                 f16x4 vh, vl;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -226,9 +223,19 @@ __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const L
 #endif
                 *(u32x4 *)dst = v;
             }
-    } else {
-        store_tiles<CT, false>(acc, p, n, oy, ox, h, valid);  // the f16x3 path has no activation variants
     }
+}
+
+template <int CT, bool SP = false>
+__device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
+                                                int h, bool valid) {
+    // (the half-wave exchange of the split store needs both lanes of a pixel: lanes l and l+32 share (oy, ox),
+    //  hence the same `valid`; invalid pairs skip the whole store)
+    if (!valid) return;
+    if (p.outfmt == OUT_C8)
+        store_split_f16<CT, SP>(acc, p, n, oy, ox, h);
+    else
+        store_tiles<CT, false>(acc, p, n, oy, ox, h, valid);  // the f16x3 path has no activation variants
 }
 
 // =================================================================================================
@@ -448,6 +455,110 @@ __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gb
             const float nv = nrm[ct][r];
             y[ct][r] *= (INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv)) * (INVERSE ? isc : sc);
         }
+}
+
+// =================================================================================================
+// gdn_f16_kernel: GDN / IGDN as a kernel of its own, in place on split rows (C8S, SP: C8SP).
+//   For layers wider than 128 channels: the fused epilogues keep accumulators + norms of one pixel tile in registers
+//   (2 x 16 CT), which fits the 256-register budget of two waves per SIMD up to CT = 4.  Wider layers run their
+//   convolution without the normalisation and this kernel after it: one more round trip of the activations, still the
+//   f16x3 arithmetic (the pre-GDN values pass through the split format: 2 x 11 bits of mantissa, |y| <= 65504 or the
+//   range guard repeats the call on fp32).  The op is pointwise, so a wave simply takes the 32 pixels of one 1-KiB
+//   group of a row (their order inside a row does not matter), loads them in the accumulator layout of
+//   v_mfma_f32_32x32x16_f16 -- lane (pixel, h) holds channels 4h..4h+3 of every plane: 8 bytes of the hi and of the
+//   lo piece -- and reuses gdn_resident_f16 / store_tiles_f16.  PERSISTENT: one 4-wave block per CU, the whole packed gamma
+//   (CT^2 x 4 KiB: 144 KiB for 192 channels) resident in LDS.
+// =================================================================================================
+template <int CT, bool INVERSE, bool SP>
+__global__ void __launch_bounds__(256, 1) gdn_f16_kernel(const LayerArgs p) {
+    constexpr int NW = 4;  // one wave per SIMD: 2 x 16 CT accumulators + norms need the 512-register budget
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *gbuf = smem;
+    float *beta_lds = (float *)(smem + CT * CT * 4096);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    for (int j = wave; j < CT * CT * 4; j += NW) glds16((const char *)p.gp + (size_t)j * 1024 + lane * 16, gbuf + j * 1024);
+    for (int i = threadIdx.x; i < CT * 32; i += NW * 64) beta_lds[i] = p.beta[i];
+    wait_vm0();
+    __syncthreads();
+
+    const int groups = (int)(c8s_row_bytes<SP>(p.OW) / 1024);  // 32-pixel groups per row
+    const long total = (long)p.N * p.OH * groups;
+    const size_t row_bytes = c8s_row_bytes<SP>(p.OW);
+    char *base = (char *)p.out;
+    for (long t = (long)blockIdx.x * NW + wave; t < total; t += (long)gridDim.x * NW) {
+        const int g = (int)(t % groups);
+        const long rest = t / groups;
+        const int oy = (int)(rest % p.OH), n = (int)(rest / p.OH);
+        const int ox = SP ? (g >> 1) * 64 + 2 * m + (g & 1) : g * 32 + m;
+        const bool valid = ox < p.OW;
+        f32x16 y[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) {
+                const size_t row = ((size_t)n * p.out_planes + 4 * ct + pl) * p.OH + oy;
+                const char *src = base + row * row_bytes + (size_t)g * 1024 + m * 16 + 8 * h;
+                const f16x4 vh = *(const f16x4 *)src, vl = *(const f16x4 *)(src + 512);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[ct][4 * pl + k] = valid ? (float)vh[k] + (float)vl[k] : 0.0f;
+            }
+        // the norms of HALF the output channel tiles at a time (y: 16 CT registers, norms 8 CT): y*y is split twice,
+        // but everything stays in registers (all CT norm tiles at once spilled hundreds of registers even at 512)
+        float mx = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2)
+                mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(y[ct][r]), __builtin_fabsf(y[ct][r + 1])));
+        float isc;
+        const float sc = pixel_scale(mx, &isc), sc2 = sc * sc;
+        constexpr int CH = CT / 2;
+        static_assert(CT % 2 == 0, "channel tiles are halved");
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x16 nrm[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nrm[c][r] = beta_lds[32 * (half * CH + c) + acc_row(r) + 4 * h] * sc2;
+#pragma unroll
+            for (int jt = 0; jt < CT; ++jt) {
+                const char *gb = gbuf + jt * (CT * 4096) + lane * 16;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    __builtin_amdgcn_sched_barrier(0);  // keep the y*y splits of later steps from being hoisted
+                    f16x8 sh, sl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = y[jt][8 * s2 + e] * sc;
+                        _Float16 a, b;
+                        split_f16(v * v, a, b);
+                        sh[e] = a;
+                        sl[e] = b;
+                    }
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int co = half * CH + c;
+                        const f16x8 gh = *(const f16x8 *)(gb + ((co * 2 + s2) * 2 + 0) * 1024);
+                        const f16x8 gl = *(const f16x8 *)(gb + ((co * 2 + s2) * 2 + 1) * 1024);
+                        nrm[c] = mfma3(gh, gl, sh, sl, nrm[c]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float nv = nrm[c][r];
+                    nrm[c][r] = y[half * CH + c][r] * (INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv)) *
+                                (INVERSE ? isc : sc);
+                }
+            // in place: every input of the tile is in registers already (lanes l and l + 32 share the pixel, hence `valid`)
+            if (valid) store_split_f16<CH, SP>(nrm, p, n, oy, ox, h, half * CH);
+        }
+    }
 }
 
 // =================================================================================================

@@ -34,9 +34,10 @@ static int launch_conv_f16_t(const LayerArgs &a, hipStream_t st) {
         case 1: return gdn ? FN<KS_, 1, true>(a, st) : FN<KS_, 1, false>(a, st);           \
         case 2: return gdn ? FN<KS_, 2, true>(a, st) : FN<KS_, 2, false>(a, st);           \
         case 4: return gdn ? FN<KS_, 4, true>(a, st) : FN<KS_, 4, false>(a, st);           \
-        case 6:                                                                            \
-            if (!gdn) return FN<KS_, 6, false>(a, st);                                     \
-            return fail(CAE_ERR_UNSUPPORTED, "f16x3: GDN with more than 128 channels is not built; use fp32"); \
+        case 6: { /* wider than 128 channels: the normalisation runs as a kernel of its own */ \
+            const int rc6 = FN<KS_, 6, false>(a, st);                                      \
+            return rc6 || !gdn ? rc6 : launch_gdn_f16(6, false, a, st);                    \
+        }                                                                                  \
         default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct);      \
     }
 

@@ -36,20 +36,21 @@ static int launch_deconv_f16_t(const LayerArgs &a, hipStream_t st) {
     }
 }
 
-#define DISPATCH_F16(FN, KS_)                                                               \
+#define DISPATCH_F16(FN, KS_, INV)                                                               \
     switch (ct) {                                                                          \
         case 1: return gdn ? FN<KS_, 1, true>(a, st) : FN<KS_, 1, false>(a, st);           \
         case 2: return gdn ? FN<KS_, 2, true>(a, st) : FN<KS_, 2, false>(a, st);           \
         case 4: return gdn ? FN<KS_, 4, true>(a, st) : FN<KS_, 4, false>(a, st);           \
-        case 6:                                                                            \
-            if (!gdn) return FN<KS_, 6, false>(a, st);                                     \
-            return fail(CAE_ERR_UNSUPPORTED, "f16x3: GDN with more than 128 channels is not built; use fp32"); \
+        case 6: { /* wider than 128 channels: the normalisation runs as a kernel of its own */ \
+            const int rc6 = FN<KS_, 6, false>(a, st);                                      \
+            return rc6 || !gdn ? rc6 : launch_gdn_f16(6, INV, a, st);                      \
+        }                                                                                  \
         default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct);      \
     }
 
 int launch_deconv_f16(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st) {
-    if (ks == 3) { DISPATCH_F16(launch_deconv_f16_t, 3) }
-    if (ks == 5) { DISPATCH_F16(launch_deconv_f16_t, 5) }
+    if (ks == 3) { DISPATCH_F16(launch_deconv_f16_t, 3, true) }
+    if (ks == 5) { DISPATCH_F16(launch_deconv_f16_t, 5, true) }
     return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
 }
 

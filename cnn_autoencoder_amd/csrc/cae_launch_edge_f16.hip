@@ -45,14 +45,44 @@ int launch_first_f16(int ks, int ct, bool gdn, const LayerArgs &a, const FirstAr
         case 1: return gdn ? launch_first_f16_t<KS_, 1, true>(a, f, st) : launch_first_f16_t<KS_, 1, false>(a, f, st); \
         case 2: return gdn ? launch_first_f16_t<KS_, 2, true>(a, f, st) : launch_first_f16_t<KS_, 2, false>(a, f, st); \
         case 4: return gdn ? launch_first_f16_t<KS_, 4, true>(a, f, st) : launch_first_f16_t<KS_, 4, false>(a, f, st); \
-        case 6:                                                                                              \
-            if (!gdn) return launch_first_f16_t<KS_, 6, false>(a, f, st);                                    \
-            return fail(CAE_ERR_UNSUPPORTED, "f16x3: GDN with more than 128 channels is not built; use fp32"); \
+        case 6: {                                                                                            \
+            const int rc6 = launch_first_f16_t<KS_, 6, false>(a, f, st);                                     \
+            return rc6 || !gdn ? rc6 : launch_gdn_f16(6, false, a, st);                                      \
+        }                                                                                                    \
         default: return fail(CAE_ERR_UNSUPPORTED, "unsupported channel tiles %d", ct);                       \
     }
     if (ks == 3) { FIRST_F16(3) }
     if (ks == 5) { FIRST_F16(5) }
     return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+}
+
+template <int CT, bool INVERSE>
+static int launch_gdn_f16_t(const LayerArgs &a, hipStream_t st) {
+    constexpr int LDS = CT * CT * 4096 + CT * 32 * 4;
+    static_assert(LDS <= 160 * 1024, "packed gamma must fit the LDS");
+    auto kern = gdn_f16_kernel<CT, INVERSE, INVERSE>;  // analysis rows are C8S, synthesis rows C8SP
+    static bool attr_done = false;
+    static int n_cu = 0;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_done = true;
+    }
+    const size_t groups = c8s_row_bytes<INVERSE>(a.OW) / 1024;
+    const size_t total = (size_t)a.N * a.OH * groups;  // wave tiles of 32 pixels
+    if (total > 0x7fffffff) return fail(CAE_ERR_ARG, "batch too large");
+    const unsigned grid = (unsigned)std::min<size_t>((total + 3) / 4, (size_t)std::max(n_cu, 1));  // persistent
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int launch_gdn_f16(int ct, bool inverse, const LayerArgs &a, hipStream_t st) {
+    if (a.outfmt != OUT_C8) return fail(CAE_ERR_UNSUPPORTED, "f16x3: stand-alone GDN needs split rows as output");
+    if (ct == 6) return inverse ? launch_gdn_f16_t<6, true>(a, st) : launch_gdn_f16_t<6, false>(a, st);
+    return fail(CAE_ERR_UNSUPPORTED, "stand-alone GDN is built for 192-channel layers (channel tiles %d)", ct);
 }
 
 template <int KS, int NW, int DEPTH>

@@ -388,7 +388,7 @@ class _Track(nn.Module):
     def precision_code(self) -> int:
         """0 = exact fp32 MFMA, 1 = f16x3 split MFMA.  Attribute `precision` ('fp32' | 'f16x3'), else the
         CAE_PRECISION environment variable, else 'f16x3' (fp32-class accuracy at ~2x the throughput;
-        channel counts the f16x3 kernels do not cover need precision='fp32')."""
+        GDN layers wider than 128 channels run their normalisation as a separate f16x3 kernel)."""
         import os
         prec = getattr(self, 'precision', None) or os.environ.get('CAE_PRECISION', 'f16x3')
         if prec not in ('fp32', 'f16x3'):
@@ -399,8 +399,6 @@ class _Track(nn.Module):
             return 0  # colour layers are stride-1 convolutions on the fp32 kernels
         if any(u.act_code for u in self._units()):
             return 0  # LeakyReLU / ReLU units (stride-1 pre-convolutions) are built on the fp32 kernels
-        if any(u.gdn is not None and u.main.out_channels > 128 for u in self._units()):
-            return 0  # the f16x3 GDN epilogue covers up to 128 channels
         return 1 if prec == 'f16x3' else 0
 
     def _units(self):

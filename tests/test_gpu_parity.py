@@ -584,3 +584,36 @@ def test_product_map_form_of_the_last_two_layers(cae, cfgkw, shape, monkeypatch,
     monkeypatch.delenv('CAE_NO_PMAP')
     d2 = (u8.int() - u8b.int()).abs()
     assert int(d2.max()) <= 1 and float((d2 > 0).float().mean()) < 5e-3
+
+
+@pytest.mark.parametrize('ks,shape', [(3, (2, 88, 72)), (3, (1, 50, 130)), (5, (1, 64, 48))])
+def test_gdn_wider_than_128_channels_stays_on_f16x3(cae, ks, shape, monkeypatch):
+    """channels_net = 192: the fused GDN epilogues hold at most 128 channels in registers, so wider
+    layers run the convolution without it and gdn_f16_kernel in place on the split rows -- still the f16x3 arithmetic
+    (effective precision 1, no fp32 repeat), same tolerance against the oracle as every other model, ragged sizes
+    (rows that do not fill their 32- / 64-pixel groups)."""
+    from oracle import cae_oracle as O
+    from cnn_autoencoder_amd import synth, _lib
+    import ctypes
+    monkeypatch.setenv('CAE_PRECISION', 'f16x3')
+    cfg = dict(synth.CANONICAL, channels_net=192, channels_bn=48, compression_level=3, kernel_size=ks)
+    state = synth.synthetic_state(cfg, seed=23)
+    model = cae.autoencoder_from_state_dict(state)
+    enc, dec = model['encoder'].module, model['decoder'].module
+    assert enc.precision_code() == 1 and dec.precision_code() == 1
+    n, h, w = shape
+    torch.manual_seed(4)
+    x = torch.rand(n, 3, h, w)
+    y_ref, _ = O.analysis_forward(x, oracle_layers(state, 'encoder'))
+    y = model['encoder'](x.cuda()).cpu()
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=RTOL, atol=ATOL * max(1.0, float(y_ref.abs().max())))
+    yq = torch.round(y_ref)
+    x_ref, brg_ref = O.synthesis_forward(yq, oracle_layers(state, 'decoder'))
+    xr, brg = dec(yq.cuda())
+    np.testing.assert_allclose(xr[0].cpu().numpy(), x_ref.numpy(), rtol=RTOL, atol=ATOL * max(1.0, float(x_ref.abs().max())))
+    for a, b in zip(brg, brg_ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=RTOL, atol=ATOL * max(1.0, float(b.abs().max())))
+    for tr in (enc, dec):
+        eff = ctypes.c_int(-1)
+        _lib.check(_lib.lib().cae_model_effective_precision(tr._handle.ptr, ctypes.byref(eff)))
+        assert eff.value == 1 and tr.fp32_fallbacks == 0
