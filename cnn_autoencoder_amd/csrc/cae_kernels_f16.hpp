@@ -22,6 +22,9 @@
 
 namespace cae {
 
+#ifndef CAE_FIRST_PIPE
+#define CAE_FIRST_PIPE 1  // conv_first_f16: hand-placed GDN schedule (gdn_resident_pipe_f16); 0: the compiler's
+#endif
 #ifndef CAE_F16_PIPE
 #define CAE_F16_PIPE 0  // 1: software-pipelined operand reads in deconv_s2_f16's K loop (measured null: the stack is power-limited)
 #endif
@@ -42,6 +45,34 @@ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
 }
+
+// The same split for two values in four instructions: v_cvt_pk_f16_f32 (hi pair), two v_fma_mix_f32 (hi x -1 + v with the
+// f16 source converted on the fly: the exact residual, as v - (float)hi) and v_cvt_pk_f16_f32 (lo pair).  The portable form
+// above compiles to 6-8 (cvt, cvt back, sub per value, packing); the f16x3 kernels split 150-200 values per 32-pixel tile
+// and their vector issue is what the matrix pipes wait for (conv_first_f16) or what costs energy (the others).
+// Bit-identical results.  -> {packed hi pair, packed lo pair} (low half = a)
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2v split2_f16(float a, float b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 ab = {a, b};
+    const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, f16x2));
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(b));
+    const f32x2 l = {l0, l1};
+    return u32x2v{hi, __builtin_bit_cast(unsigned, __builtin_convertvector(l, f16x2))};
+}
+
+// max(mx, |a|, |b|) as ONE v_max3_f32 with source modifiers (the portable fmaxf / fabsf form canonicalises each operand
+// first: 3.5 instructions per pair measured in conv_first_f16; every tile takes two such maxima over 16 CT values)
+__device__ __forceinline__ float absmax3(float mx, float a, float b) {
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(mx));
+    return r;
+}
+
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 // ---- range guard ---------------------------------------------------------------------------------------
 // f16 carries 5 exponent bits: a value above F16_MAX cannot be stored in the split format (hi = inf).  Every
@@ -98,7 +129,7 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&yy)[PTA][CT], const Laye
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; r += 2)
-                mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(y[PT0 + pt][ct][r]), __builtin_fabsf(y[PT0 + pt][ct][r + 1])));
+                mx = absmax3(mx, y[PT0 + pt][ct][r], y[PT0 + pt][ct][r + 1]);
         psc[pt] = pixel_scale(mx, &pisc[pt]);
         init_acc<CT>(nrm[pt], p.beta, h, 1.0f);
         const float sc2 = psc[pt] * psc[pt];
@@ -128,15 +159,16 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&yy)[PTA][CT], const Laye
         for (int s = 0; s < 2; ++s) {
             f16x8 sh[PT], sl[PT];
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt)
+            for (int pt = 0; pt < PT; ++pt) {
+                u32x4v hw, lw;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = y[PT0 + pt][jt][8 * s + e] * psc[pt];
-                    _Float16 a, b;
-                    split_f16(v * v, a, b);
-                    sh[pt][e] = a;
-                    sl[pt][e] = b;
+                for (int e = 0; e < 4; ++e) {
+                    const float v0 = y[PT0 + pt][jt][8 * s + 2 * e] * psc[pt], v1 = y[PT0 + pt][jt][8 * s + 2 * e + 1] * psc[pt];
+                    { const u32x2v t_ = split2_f16(v0 * v0, v1 * v1); hw[e] = t_[0]; lw[e] = t_[1]; }
                 }
+                sh[pt] = __builtin_bit_cast(f16x8, hw);
+                sl[pt] = __builtin_bit_cast(f16x8, lw);
+            }
 #pragma unroll
             for (int co = 0; co < CT; ++co) {
                 const f16x8 gh = *(const f16x8 *)(gb + ((co * 2 + s) * 2 + 0) * 1024);
@@ -195,24 +227,18 @@ __device__ __forceinline__ void store_split_f16(const f32x16 (&acc)[CT], const L
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; r += 2)
-                mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(acc[ct][r]), __builtin_fabsf(acc[ct][r + 1])));
+                mx = absmax3(mx, acc[ct][r], acc[ct][r + 1]);
         raise_if_over(mx, p.flag);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int plane = 4 * (ct0 + ct) + g;
-                f16x4 vh, vl;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    _Float16 a, b;
-                    split_f16(acc[ct][4 * g + k], a, b);
-                    vh[k] = a;
-                    vl[k] = b;
-                }
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const u32x2 yh = __builtin_bit_cast(u32x2, vh), xl = __builtin_bit_cast(u32x2, vl);
+                u32x2 yh, xl;
+                { const u32x2v t_ = split2_f16(acc[ct][4 * g + 0], acc[ct][4 * g + 1]); yh[0] = t_[0]; xl[0] = t_[1]; }
+                { const u32x2v t_ = split2_f16(acc[ct][4 * g + 2], acc[ct][4 * g + 3]); yh[1] = t_[0]; xl[1] = t_[1]; }
                 const auto r0 = __builtin_amdgcn_permlane32_swap(yh[0], xl[0], false, false);
                 const auto r1 = __builtin_amdgcn_permlane32_swap(yh[1], xl[1], false, false);
                 const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
@@ -416,7 +442,7 @@ __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gb
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; r += 2)
-            mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(y[ct][r]), __builtin_fabsf(y[ct][r + 1])));
+            mx = absmax3(mx, y[ct][r], y[ct][r + 1]);
     float isc;
     const float sc = pixel_scale(mx, &isc), sc2 = sc * sc;
 #pragma unroll
@@ -429,15 +455,13 @@ __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gb
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             __builtin_amdgcn_sched_barrier(0);  // keep the y*y splits of later steps from being hoisted (registers)
-            f16x8 sh, sl;
+            u32x4v hw, lw;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = y[jt][8 * s + e] * sc;
-                _Float16 a, b;
-                split_f16(v * v, a, b);
-                sh[e] = a;
-                sl[e] = b;
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = y[jt][8 * s + 2 * e] * sc, v1 = y[jt][8 * s + 2 * e + 1] * sc;
+                { const u32x2v t_ = split2_f16(v0 * v0, v1 * v1); hw[e] = t_[0]; lw[e] = t_[1]; }
             }
+            const f16x8 sh = __builtin_bit_cast(f16x8, hw), sl = __builtin_bit_cast(f16x8, lw);
 #pragma unroll
             for (int co = 0; co < CT; ++co) {
                 // (at most two fragment pairs in flight: with all CT hoisted the 256-register kernels spilled)
@@ -448,6 +472,85 @@ __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gb
             }
         }
     }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float nv = nrm[ct][r];
+            y[ct][r] *= (INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv)) * (INVERSE ? isc : sc);
+        }
+}
+
+// gdn_resident_f16 with a hand-placed schedule, for kernels that are NOT at the power cap (conv_first_f16: MFMA pipes
+// busy 0.29 of the cycles at 1.9 GHz).  The compiler's form alternates per 16-deep step [split 8 squares: ~30 VALU]
+// [per channel tile: 2 ds_read -> lgkmcnt(0) -> 3 MFMAs], i.e. the VALU work and 4 LDS latencies per step are serial
+// with the MFMAs of the same wave.  Here every MFMA is followed, inside its own 32-cycle shadow, by a slice of the NEXT
+// step's split (12 slots: 4 value pairs x {scale + square, split2_f16, -}) and the gamma fragments of the
+// next channel tile are read one tile ahead into a second register set.  `sched_barrier(0)` fences pin the order.
+// Same operations on the same values in the same accumulation order: results identical to gdn_resident_f16.
+template <int CT, bool INVERSE>
+__device__ __forceinline__ void gdn_resident_pipe_f16(f32x16 (&y)[CT], const char *gbuf, const float *beta_lds, int lane) {
+    const int h = lane >> 5;
+    f32x16 nrm[CT];
+    float mx = 0.0f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+            mx = absmax3(mx, y[ct][r], y[ct][r + 1]);
+    float isc;
+    const float sc = pixel_scale(mx, &isc), sc2 = sc * sc;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nrm[ct][r] = beta_lds[32 * ct + acc_row(r) + 4 * h] * sc2;
+
+    constexpr int NSTEP = 2 * CT, CHUNKS = 3 * CT;          // 16-deep steps; MFMAs (= slots for split slices) per step
+    constexpr int PPC = (12 + CHUNKS - 1) / CHUNKS;          // split slices per MFMA slot
+    u32x4v shw[2], slw[2];                                   // squares of step (set): packed hi / lo pairs
+    f16x8 g[2][2];                                           // gamma fragments [set][hi, lo]
+    float q[2];
+    auto slice = [&](int step, int part) {  // slice `part` (0..11) of the split of step `step` into set step & 1
+        // (the empty asm statements give each slice's results a use where the slice stands: without them the compiler sinks
+        //  all three slices of a pair to the last one; contraction off: round(v v) - hi as in split_f16, not fma(v, v, -hi))
+#pragma clang fp contract(off)
+        const int jt = step >> 1, s2 = step & 1, pr = part / 3, set = step & 1;
+        if (part % 3 == 0) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float v = y[jt][8 * s2 + 2 * pr + k] * sc;
+                q[k] = v * v;
+            }
+            asm volatile("" : "+v"(q[0]), "+v"(q[1]));
+        } else if (part % 3 == 1) {
+            { const u32x2v t_ = split2_f16(q[0], q[1]); shw[set][pr] = t_[0]; slw[set][pr] = t_[1]; }
+            asm volatile("" : "+v"(shw[set][pr]), "+v"(slw[set][pr]));
+        }
+    };
+    auto load_g = [&](int step, int co, int set) {
+        const char *gb = gbuf + (step >> 1) * (CT * 4096) + lane * 16;
+        g[set][0] = *(const f16x8 *)(gb + ((co * 2 + (step & 1)) * 2 + 0) * 1024);
+        g[set][1] = *(const f16x8 *)(gb + ((co * 2 + (step & 1)) * 2 + 1) * 1024);
+    };
+#pragma unroll
+    for (int part = 0; part < 12; ++part) slice(0, part);
+    load_g(0, 0, 0);
+    static_for<NSTEP * CT>([&](auto it) {
+        constexpr int i = decltype(it)::value, step = i / CT, co = i % CT;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (i + 1 < NSTEP * CT) load_g((i + 1) / CT, (i + 1) % CT, (i + 1) & 1);
+        const f16x8 gh = g[i & 1][0], gl = g[i & 1][1];
+        const f16x8 bh = __builtin_bit_cast(f16x8, shw[step & 1]), bl = __builtin_bit_cast(f16x8, slw[step & 1]);
+        static_for<3>([&](auto mt) {
+            constexpr int m = decltype(mt)::value, chunk = co * 3 + m;
+            nrm[co] = __builtin_amdgcn_mfma_f32_32x32x16_f16(m == 2 ? gl : gh, m == 1 ? bl : bh, nrm[co], 0, 0, 0);
+            if constexpr (step + 1 < NSTEP) {
+#pragma unroll
+                for (int part = chunk * PPC; part < (chunk + 1) * PPC && part < 12; ++part) slice(step + 1, part);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -511,7 +614,7 @@ __global__ void __launch_bounds__(256, 1) gdn_f16_kernel(const LayerArgs p) {
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; r += 2)
-                mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(y[ct][r]), __builtin_fabsf(y[ct][r + 1])));
+                mx = absmax3(mx, y[ct][r], y[ct][r + 1]);
         float isc;
         const float sc = pixel_scale(mx, &isc), sc2 = sc * sc;
         constexpr int CH = CT / 2;
@@ -529,15 +632,13 @@ __global__ void __launch_bounds__(256, 1) gdn_f16_kernel(const LayerArgs p) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     __builtin_amdgcn_sched_barrier(0);  // keep the y*y splits of later steps from being hoisted
-                    f16x8 sh, sl;
+                    u32x4v hw, lw;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = y[jt][8 * s2 + e] * sc;
-                        _Float16 a, b;
-                        split_f16(v * v, a, b);
-                        sh[e] = a;
-                        sl[e] = b;
+                    for (int e = 0; e < 4; ++e) {
+                        const float v0 = y[jt][8 * s2 + 2 * e] * sc, v1 = y[jt][8 * s2 + 2 * e + 1] * sc;
+                        { const u32x2v t_ = split2_f16(v0 * v0, v1 * v1); hw[e] = t_[0]; lw[e] = t_[1]; }
                     }
+                    const f16x8 sh = __builtin_bit_cast(f16x8, hw), sl = __builtin_bit_cast(f16x8, lw);
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
                         const int co = half * CH + c;
@@ -694,7 +795,7 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
             for (int r = 0; r < 16; ++r) acc[ct][r] = bias_lds[32 * ct + acc_row(r) + 4 * h];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            f16x8 bh, bl;
+            u32x4v bhw, blw;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 // tap index of this lane half: 4s + 2h + half  (compile-time per h)
@@ -704,15 +805,11 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
                 f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
                 if (o0 >= 0) v0 = *(const f32x4 *)(hb + o0);
                 if (o1 >= 0) v1 = *(const f32x4 *)(hb + o1);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float v = h ? v1[c] : v0[c];
-                    _Float16 a, b;
-                    split_f16(v, a, b);
-                    bh[4 * half + c] = a;
-                    bl[4 * half + c] = b;
-                }
+                const f32x4 v = h ? v1 : v0;
+                { const u32x2v t_ = split2_f16(v[0], v[1]); bhw[2 * half] = t_[0]; blw[2 * half] = t_[1]; }
+                { const u32x2v t_ = split2_f16(v[2], v[3]); bhw[2 * half + 1] = t_[0]; blw[2 * half + 1] = t_[1]; }
             }
+            const f16x8 bh = __builtin_bit_cast(f16x8, bhw), bl = __builtin_bit_cast(f16x8, blw);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const f16x8 ah = *(const f16x8 *)(wb + ((s * CT + ct) * 2 + 0) * 1024);
@@ -720,15 +817,22 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
                 acc[ct] = mfma3(ah, al, bh, bl, acc[ct]);
             }
         }
-        if constexpr (GDN) gdn_resident_f16<CT, false>(acc, gbuf, beta_lds, lane);
-        const int oy = ty * TY + 2 * wave + (m >> 4), ox = tx * TX + (m & 15);
-        store_tiles_f16<CT>(acc, p, n, oy, ox, h, oy < p.OH && ox < p.OW);
-
-        // refill this wave's halo: LDS operations of one wave execute in order, the wave barriers only keep the
-        // compiler from moving the stores above the reads of the tile just finished (or the next reads above them)
+        // refill this wave's halo as soon as the convolution has read it: LDS operations of one wave execute in order,
+        // the wave barriers only keep the compiler from moving the LDS stores above the reads of the tile just finished
+        // (or the next tile's reads above them).  BEFORE this tile's output stores on purpose: vmcnt counts loads and
+        // stores together in issue order, and with the commit after the stores the wait for the prefetched pixels came
+        // out as vmcnt(11..0) on the merged control flow -- a drain of all 16 output stores (an HBM write round trip) per
+        // tile.  Here the only older operations are the previous tile's stores, a whole tile period old.
         __builtin_amdgcn_wave_barrier();
         if (has_next) commit();
         __builtin_amdgcn_wave_barrier();
+#if CAE_FIRST_PIPE
+        if constexpr (GDN) gdn_resident_pipe_f16<CT, false>(acc, gbuf, beta_lds, lane);
+#else
+        if constexpr (GDN) gdn_resident_f16<CT, false>(acc, gbuf, beta_lds, lane);
+#endif
+        const int oy = ty * TY + 2 * wave + (m >> 4), ox = tx * TX + (m & 15);
+        store_tiles_f16<CT>(acc, p, n, oy, ox, h, oy < p.OH && ox < p.OW);
     }
 }
 
@@ -1382,7 +1486,7 @@ static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t rows,
         f16x8 vh, vl;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(a[k]), __builtin_fabsf(b[k])));
+            mx = absmax3(mx, a[k], b[k]);
             _Float16 x, y;
             split_f16(a[k], x, y);
             vh[k] = x;

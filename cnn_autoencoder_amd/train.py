@@ -370,17 +370,19 @@ def synthesis_forward(track, yq: torch.Tensor):
 
 def setup_optim(model: Dict[str, nn.Module], trainable_modules: Sequence[str] = ('encoder', 'decoder', 'fact_ent'),
                 learning_rate: float = 1e-4, aux_learning_rate: float = 1e-3, weight_decay: float = 0.0,
-                algo=torch.optim.Adam) -> Dict[str, torch.optim.Optimizer]:
+                algo=torch.optim.Adam, capturable: bool = False) -> Dict[str, torch.optim.Optimizer]:
     """One optimiser per trainable module; parameters whose name contains 'quantiles' or 'aux' go to a separate
-    ``<module>_aux`` optimiser (train_cae_ms.py:584-641)."""
+    ``<module>_aux`` optimiser (train_cae_ms.py:584-641).  capturable: step counters on the device, as
+    GraphedTrainStep needs them."""
     opts: Dict[str, torch.optim.Optimizer] = {}
+    extra = dict(capturable=True) if capturable else {}
     for k in trainable_modules:
         pars, aux = [], []
         for name, par in model[k].named_parameters():
             (aux if ('quantiles' in name.lower() or 'aux' in name.lower()) else pars).append(par)
-        opts[k] = algo([dict(params=pars, lr=learning_rate, weight_decay=weight_decay)])
+        opts[k] = algo([dict(params=pars, lr=learning_rate, weight_decay=weight_decay)], **extra)
         if aux:
-            opts[k + '_aux'] = algo([dict(params=aux, lr=aux_learning_rate, weight_decay=weight_decay)])
+            opts[k + '_aux'] = algo([dict(params=aux, lr=aux_learning_rate, weight_decay=weight_decay)], **extra)
     return opts
 
 
@@ -401,6 +403,69 @@ def train_step(x: torch.Tensor, model, criterion, optimizers, forward_func=None,
         opt.step()
         opt.zero_grad()
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
+
+
+class GraphedTrainStep:
+    """train_step replayed from HIP graphs.  One iteration of the reference's loop is ~600 kernel launches of a few
+    microseconds each (the entropy model's density, the losses, clipping and four Adam instances are element-wise
+    torch ops): launched one by one the GPU idles about half of the step.  Captured once --
+
+      graph 1: forward_func -> criterion -> backward -> aux-loss backward        (gradients land in static .grad buffers)
+      [reducer.reduce(): the bucketed all-reduce stays outside, RCCL picks its own launch order]
+      graph 2: clip_grad_norm_(1.0) -> step -> zero_grad per optimiser
+
+    -- a step is a copy of the batch into the static input and two replays.  Same arithmetic as train_step; the uniform
+    noise of the entropy bottleneck is drawn inside the graph (the generator's offset advances per replay).  Needs
+    optimisers built with setup_optim(capturable=True), a fixed batch shape, and `warmup` ordinary steps first (they are
+    real training steps: lazy initialisation and the optimiser state must exist before capture).
+    The returned loss_dict holds STATIC tensors: read them before the next call."""
+
+    def __init__(self, x_example: torch.Tensor, model, criterion, optimizers, forward_func=None,
+                 reducer: 'GradReducer' = None, warmup: int = 3):
+        from .criteria import setup_forward_func
+        self.model, self.criterion, self.optimizers, self.reducer = model, criterion, optimizers, reducer
+        self.forward_func = forward_func or setup_forward_func()
+        self.x = x_example.detach().clone()
+        for opt in optimizers.values():
+            if not opt.defaults.get('capturable', False):
+                raise ValueError('GraphedTrainStep needs optimisers built with capturable=True (setup_optim(capturable=True))')
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                self._forward_backward()
+                if reducer is not None:
+                    reducer.reduce()
+                self._update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_fb, self.g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            self.loss_dict = self._forward_backward()
+        with torch.cuda.graph(self.g_up, pool=self.g_fb.pool()):
+            self._update()
+
+    def _forward_backward(self):
+        output = self.forward_func(self.x, self.model)
+        loss_dict = self.criterion(inputs=self.x, outputs=output, net=self.model)
+        torch.mean(loss_dict['loss']).backward()
+        if 'entropy_loss' in loss_dict:
+            torch.mean(loss_dict['entropy_loss']).backward()
+        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
+
+    def _update(self):
+        for opt in self.optimizers.values():
+            nn.utils.clip_grad_norm_(opt.param_groups[0]['params'], max_norm=1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=False)  # the .grad buffers are part of the graphs
+
+    def __call__(self, x: torch.Tensor):
+        self.x.copy_(x, non_blocking=True)
+        self.g_fb.replay()
+        if self.reducer is not None:
+            self.reducer.reduce()
+        self.g_up.replay()
+        return self.loss_dict
 
 
 class GradReducer:
