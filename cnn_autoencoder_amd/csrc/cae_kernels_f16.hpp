@@ -229,11 +229,12 @@ __device__ __forceinline__ void store_split_f16(const f32x16 (&acc)[CT], const L
             for (int r = 0; r < 16; r += 2)
                 mx = absmax3(mx, acc[ct][r], acc[ct][r + 1]);
         raise_if_over(mx, p.flag);
+        const size_t row_bytes = c8s_row_bytes<SP>(p.OW), plane_bytes = (size_t)p.OH * row_bytes;
+        char *dst0 = out + (((size_t)n * p.out_planes + 4 * ct0) * p.OH + oy) * row_bytes + c8s_piece<SP>(ox) + 512 * h;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int plane = 4 * (ct0 + ct) + g;
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 u32x2 yh, xl;
@@ -242,8 +243,8 @@ __device__ __forceinline__ void store_split_f16(const f32x16 (&acc)[CT], const L
                 const auto r0 = __builtin_amdgcn_permlane32_swap(yh[0], xl[0], false, false);
                 const auto r1 = __builtin_amdgcn_permlane32_swap(yh[1], xl[1], false, false);
                 const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
-                const size_t row = ((size_t)n * p.out_planes + plane) * p.OH + oy;
-                char *dst = out + row * c8s_row_bytes<SP>(p.OW) + c8s_piece<SP>(ox) + 512 * h;
+                char *dst = dst0;
+                dst0 += plane_bytes;  // next plane: one 64-bit add of a uniform (no per-plane 64-bit multiplies)
 #ifdef CAE_EXP_F16_NOSTORE  // timing-only ablation: activations are computed but not written (wrong results)
                 if (p.N < 0)
 #endif
@@ -780,7 +781,9 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
     const char *hb = whalo + ((2 * (m >> 4)) * WH + 2 * (m & 15)) * 16;
     const char *wb = wbuf + lane * 16;
     // (starting the two waves of a SIMD half a tile period apart, so that one's VALU phase meets the other's MFMA
-    //  phase, was measured: no effect -- profiles/r01_experiments.md)
+    //  phase, was measured: no effect -- profiles/r01_experiments.md: free-running waves drift back.)
+    // Holding the two waves of a SIMD in opposite phases with block barriers (upper half one phase behind, GDN of one
+    // wave against convolution / split / store of the other) was measured too: 1.39 vs 1.26 ms (r02_experiments.md 11).
     for (; t < total; t += gridDim.x) {
         const int tn = t + gridDim.x;
         const bool has_next = tn < total;
