@@ -416,18 +416,31 @@ class SlideCoder:
             # dequantiser fused into the layout conversion in front of the first synthesis layer
             rec, guard = self.dec.forward_symbols_u8(sym.reshape(n, self.eb.channels, lh, lw), self.eb, defer=True)
             sse = self.tile_sse(rec, t)
+            # the per-tile errors go to the host on the copy stream, behind an event of their own: read with a plain
+            # `.cpu()` on the main stream they queued behind whatever had been launched since (the next batch's kernels),
+            # the main thread sat in that copy until the GPU had drained, and every step began with a ~0.2 ms idle gap
+            got = torch.cuda.Event()
+            got.record(main)
+            sse_host = self._pin(('s', k % 4), (n,), torch.float64)  # (finalised two batches later: 4 sets)
+            with torch.cuda.stream(copy_up):
+                copy_up.wait_event(got)
+                sse_host.copy_(sse, non_blocking=True)
+                landed = torch.cuda.Event(blocking=True)
+                landed.record(copy_up)
+            sse.record_stream(copy_up)
             nbytes = ([payloads.nbytes(i) + 16 for i in range(len(payloads))] if hasattr(payloads, 'nbytes')
                       else [len(p) + 16 for p in payloads])
-            return sse, nbytes, h * w * c, guard, (k, payloads)
+            return (sse_host, landed), nbytes, h * w * c, guard, (k, payloads)
 
-        pending = []  # (sse tensor on GPU, nbytes list, samples, range guard, (k, payloads))
+        pending = []  # ((pinned sse, landed event), nbytes list, samples, range guard, (k, payloads))
 
         def finalize(entry):
-            """statistics of a finished batch (its range check needs its kernels done: sse.cpu() synchronises with them);
+            """statistics of a finished batch (its range check needs its kernels done: the `landed` event is behind them);
             done with a lag of two batches inside the loop, so the payload buffers are released as the run proceeds --
             released all at once after the loop they cost ~2 ms per batch of pure host time inside the timed region"""
-            sse, nbytes, samples, guard, (k, payloads) = entry
-            sse_host = sse.cpu().tolist()
+            (sse_pinned, landed), nbytes, samples, guard, (k, payloads) = entry
+            landed.synchronize()  # this batch's kernels and the copy of its errors are done (the range flag too)
+            sse_host = sse_pinned.tolist()
             if guard.overflowed():  # f16x3 range guard: repeat this batch's synthesis on the fp32 kernels
                 t = batches[k]
                 rec = self._redo_synthesis(payloads, t.shape[1], t.shape[2], main)
