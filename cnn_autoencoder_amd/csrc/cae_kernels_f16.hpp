@@ -165,6 +165,10 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&yy)[PTA][CT], const Laye
                 for (int e = 0; e < 4; ++e) {
                     const float v0 = y[PT0 + pt][jt][8 * s + 2 * e] * psc[pt], v1 = y[PT0 + pt][jt][8 * s + 2 * e + 1] * psc[pt];
                     { const u32x2v t_ = split2_f16(v0 * v0, v1 * v1); hw[e] = t_[0]; lw[e] = t_[1]; }
+                    if constexpr (!INVERSE) {  // keep y sc: y rsqrt(n) = (y sc) rsqrt(n sc^2), one multiply less at the end
+                        y[PT0 + pt][jt][8 * s + 2 * e] = v0;
+                        y[PT0 + pt][jt][8 * s + 2 * e + 1] = v1;
+                    }
                 }
                 sh[pt] = __builtin_bit_cast(f16x8, hw);
                 sl[pt] = __builtin_bit_cast(f16x8, lw);
@@ -181,13 +185,16 @@ __device__ __forceinline__ void gdn_stages_f16(f32x16 (&yy)[PTA][CT], const Laye
     }
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-        const float back = INVERSE ? pisc[pt] : psc[pt];  // sqrt(n / sc^2) = sqrt(n) / sc,  rsqrt(n / sc^2) = rsqrt(n) sc
+        // nrm = n sc^2:  sqrt(n) = sqrt(nrm) / sc;  y rsqrt(n) = (y sc) rsqrt(nrm), and y already holds y sc
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float nv = nrm[pt][ct][r];
-                y[PT0 + pt][ct][r] *= (INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv)) * back;
+                if constexpr (INVERSE)
+                    y[PT0 + pt][ct][r] *= __builtin_amdgcn_sqrtf(nv) * pisc[pt];
+                else
+                    y[PT0 + pt][ct][r] *= __builtin_amdgcn_rsqf(nv);
             }
     }
 }
@@ -461,6 +468,10 @@ __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gb
             for (int e = 0; e < 4; ++e) {
                 const float v0 = y[jt][8 * s + 2 * e] * sc, v1 = y[jt][8 * s + 2 * e + 1] * sc;
                 { const u32x2v t_ = split2_f16(v0 * v0, v1 * v1); hw[e] = t_[0]; lw[e] = t_[1]; }
+                if constexpr (!INVERSE) {  // keep y sc (see gdn_stages_f16)
+                    y[jt][8 * s + 2 * e] = v0;
+                    y[jt][8 * s + 2 * e + 1] = v1;
+                }
             }
             const f16x8 sh = __builtin_bit_cast(f16x8, hw), sl = __builtin_bit_cast(f16x8, lw);
 #pragma unroll
@@ -478,7 +489,10 @@ __device__ __forceinline__ void gdn_resident_f16(f32x16 (&y)[CT], const char *gb
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float nv = nrm[ct][r];
-            y[ct][r] *= (INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv)) * (INVERSE ? isc : sc);
+            if constexpr (INVERSE)
+                y[ct][r] *= __builtin_amdgcn_sqrtf(nv) * isc;
+            else
+                y[ct][r] *= __builtin_amdgcn_rsqf(nv);  // y holds y sc
         }
 }
 
@@ -521,6 +535,7 @@ __device__ __forceinline__ void gdn_resident_pipe_f16(f32x16 (&y)[CT], const cha
             for (int k = 0; k < 2; ++k) {
                 const float v = y[jt][8 * s2 + 2 * pr + k] * sc;
                 q[k] = v * v;
+                if constexpr (!INVERSE) y[jt][8 * s2 + 2 * pr + k] = v;  // keep y sc (see gdn_stages_f16)
             }
             asm volatile("" : "+v"(q[0]), "+v"(q[1]));
         } else if (part % 3 == 1) {
@@ -557,7 +572,10 @@ __device__ __forceinline__ void gdn_resident_pipe_f16(f32x16 (&y)[CT], const cha
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float nv = nrm[ct][r];
-            y[ct][r] *= (INVERSE ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv)) * (INVERSE ? isc : sc);
+            if constexpr (INVERSE)
+                y[ct][r] *= __builtin_amdgcn_sqrtf(nv) * isc;
+            else
+                y[ct][r] *= __builtin_amdgcn_rsqf(nv);  // y holds y sc
         }
 }
 
@@ -873,16 +891,16 @@ __device__ __forceinline__ void store_pmap_f16(const f32x16 (&y)[CT], const Laye
     for (int jt = 0; jt < CT; ++jt)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            f16x8 sh, sl;
+            u32x4v hw, lw;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = y[jt][8 * s + e];
-                mx = __builtin_fmaxf(mx, __builtin_fabsf(v));
-                _Float16 a, b;
-                split_f16(v, a, b);
-                sh[e] = a;
-                sl[e] = b;
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = y[jt][8 * s + 2 * e], v1 = y[jt][8 * s + 2 * e + 1];
+                mx = absmax3(mx, v0, v1);
+                const u32x2v t_ = split2_f16(v0, v1);
+                hw[e] = t_[0];
+                lw[e] = t_[1];
             }
+            const f16x8 sh = __builtin_bit_cast(f16x8, hw), sl = __builtin_bit_cast(f16x8, lw);
             const f16x8 ah = *(const f16x8 *)(ab + ((jt * 2 + s) * 2 + 0) * 1024);
             const f16x8 al = *(const f16x8 *)(ab + ((jt * 2 + s) * 2 + 1) * 1024);
             pm = mfma3(ah, al, sh, sl, pm);
