@@ -229,10 +229,16 @@ static std::vector<_Float16> pack_pmap_f16(const float *w, int cin, int cout, in
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
                     const int r = 8 * s2 + e;
-                    const int row = lane & 31, tap = row / 3, c = row % 3;
+                    // map row (lane & 31) = slot of the record as pmap_gather_kernel reads it (cae_kernels_f16.hpp):
+                    // [taps 4, 5, 7, 8 | taps 3, 6, pad 2 | taps 1, 2, pad 2 | tap 0, pad 1] x 3 channels
+                    static const int slot_tap[32] = {4, 4, 4, 5, 5, 5, 7, 7, 7, 8, 8, 8, 3, 3, 3, 6, 6, 6, -1, -1,
+                                                     1, 1, 1, 2, 2, 2, -1, -1, 0, 0, 0, -1};
+                    static const int slot_c[32] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 0,
+                                                   0, 1, 2, 0, 1, 2, 0, 0, 0, 1, 2, 0};
+                    const int row = lane & 31, tap = slot_tap[row], c = slot_c[row];
                     const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     float v = 0.0f;
-                    if (tap < 9 && c < cout && j < cin) v = w[((size_t)j * cout + c) * 9 + tap];
+                    if (tap >= 0 && c < cout && j < cin) v = w[((size_t)j * cout + c) * 9 + tap];
                     _Float16 hi, lo;
                     split_half(v, hi, lo);
                     const size_t base = (((size_t)jt * 2 + s2) * 2) * 512;

@@ -867,7 +867,8 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
 // channels: 128 B instead of 512 B written, and the last layer becomes a 4-term gather (pmap_gather_kernel) that
 // reads 128 B per pixel instead of 512 B.  Same fp32-class arithmetic (f16x3 products, fp32 accumulation); only the
 // summation order of the last layer changes.
-//   packed map: [jt][s(2)][hl(2)][64 lanes][8 f16]: A(row = lane&31 = 3 tap + c, k = 32jt + row(8s + e) + 4(lane>>5))
+//   packed map: [jt][s(2)][hl(2)][64 lanes][8 f16]: A(row = lane&31 = record slot (tap, c) in the order pmap_gather_kernel
+//   reads them, k = 32jt + row(8s + e) + 4(lane>>5))
 //   map in HBM: fp32 [N][OH][2][OW/2][32]: rows split by pixel parity (as C8SP), because a sub-pixel phase produces every
 //   second pixel: the 32 pixels of a wave are then 32 consecutive 128-byte records.
 __host__ __device__ __forceinline__ size_t pmap_record(int n, int OH, int OW, int oy, int ox) {
@@ -930,13 +931,15 @@ __device__ __forceinline__ void store_pmap_f16(const f32x16 (&y)[CT], const Laye
 
 // out[n][2a+py][2b+px][c] = bias[c] + sum over (d, dx) of P[a-d][b-dx][(2d+py+1)*3 + (2dx+px+1)][c]   (k = 3)
 // block = 16 x 16 input pixels (a, b) -> 32 x 32 output pixels.  The 17 x 17 records (one halo row / column) are staged
-// in LDS with coalesced 16-byte loads (record pitch 33 floats: conflict-free), every thread sums the <= 4 terms of its
+// in LDS with coalesced 16-byte loads (record pitch 36 floats), every thread sums the <= 4 terms of its
 // 2 x 2 output pixels, and uint8 output rows leave through LDS as whole dwords (the per-thread byte stores of the first
 // version made this kernel as slow as the layer it replaces).  uint8 HWC (x255, clip, truncate) or fp32 NCHW.
 static __global__ void __launch_bounds__(256) pmap_gather_kernel(const float *pm, const float *bias, void *out, int N, int H,
                                                                int W, int cout, int fmt, int tiles_x, int tiles_y) {
-    constexpr int T = 16, R = T + 1, PITCH = 33;
-    __shared__ float rec[R * R * PITCH];
+    // record pitch 36 floats: 16-byte aligned pieces (vector LDS stores / loads) and conflict-free 16-byte reads of 16
+    // consecutive records (36 i mod 64 steps through all 16 four-bank groups)
+    constexpr int T = 16, R = T + 1, PITCH = 36;
+    __shared__ __attribute__((aligned(16))) float rec[R * R * PITCH];
     __shared__ __attribute__((aligned(4))) uint8_t orow[2 * T][2 * T * 3 + 4];
     int bid = blockIdx.x;
     const int tx = bid % tiles_x;
@@ -944,17 +947,23 @@ static __global__ void __launch_bounds__(256) pmap_gather_kernel(const float *pm
     const int ty = bid % tiles_y;
     const int n = bid / tiles_y;
     const int a0 = ty * T, b0 = tx * T;
-    for (int i = threadIdx.x; i < R * R * 8; i += 256) {
+    // all of a thread's loads first, then its LDS stores: written as one loop the compiler kept ONE load in flight per
+    // thread (load, vmcnt(0), LDS store, next): 12 KB in flight per CU, the kernel ran at 3 TB/s of its 1.2 GB
+    constexpr int NIT = (R * R * 8 + 255) / 256;
+    f32x4 stage[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * 256;
         const int q = i & 7, r = i >> 3;
         const int ra = r / R, rb = r - ra * R;
         const int a = a0 + ra, b = b0 + rb;
-        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};  // records outside the image contribute nothing
-        if (a < H && b < W) v = *(const f32x4 *)(pm + pmap_record(n, H, W, a, b) + 4 * q);
-        float *d = rec + r * PITCH + 4 * q;
-        d[0] = v[0];
-        d[1] = v[1];
-        d[2] = v[2];
-        d[3] = v[3];
+        stage[it] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // records outside the image contribute nothing
+        if (i < R * R * 8 && a < H && b < W) stage[it] = *(const f32x4 *)(pm + pmap_record(n, H, W, a, b) + 4 * q);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < R * R * 8) *(f32x4 *)(rec + (i >> 3) * PITCH + 4 * (i & 7)) = stage[it];
     }
     __syncthreads();
     const int la = threadIdx.x >> 4, lb = threadIdx.x & 15;
@@ -962,13 +971,28 @@ static __global__ void __launch_bounds__(256) pmap_gather_kernel(const float *pm
     const float *p00 = rec + (la * R + lb) * PITCH, *p01 = p00 + PITCH, *p10 = p00 + R * PITCH, *p11 = p10 + PITCH;
     const int OH = 2 * H, OW = 2 * W;
     const bool u8 = fmt == OUT_U8HWC;
-    for (int c = 0; c < cout; ++c) {
+    // The record's 32 slots are ordered by WHO reads them (pack_pmap_f16, cae_api.hip), 3 channels per tap t = 3 ky + kx:
+    //   [0..11] taps 4, 5, 7, 8: this pixel's own terms of its four outputs      (py = 0: ky = 1 at row a; py = 1: ky = 2
+    //   [12..17] taps 3, 6: terms for the outputs of pixel (a, b - 1): read from p01 = record (a, b + 1); at row a and
+    //   [20..25] taps 1, 2: terms for pixel (a - 1, b): read from p10 = record (a + 1, b);           ky = 0 at row a + 1;
+    //   [28..30] tap 0:     term for pixel (a - 1, b - 1): read from p11 = record (a + 1, b + 1)     same for columns)
+    // so a thread needs eight 16- / 8-byte LDS reads instead of 27 scalar ones.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x4 s0 = *(const f32x4 *)(p00), s1 = *(const f32x4 *)(p00 + 4), s2 = *(const f32x4 *)(p00 + 8);
+    const f32x4 l0 = *(const f32x4 *)(p01 + 12), u0 = *(const f32x4 *)(p10 + 20), d0 = *(const f32x4 *)(p11 + 28);
+    const f32x2 l1 = *(const f32x2 *)(p01 + 16), u1 = *(const f32x2 *)(p10 + 24);
+    const float self[12] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]};
+    const float left[6] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1]};  // taps 3, 6 of record (a, b + 1)
+    const float up[6] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1]};    // taps 1, 2 of (a + 1, b)
+    const float diag[3] = {d0[0], d0[1], d0[2]};                       // tap 0 of (a + 1, b + 1)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (c >= cout) break;
         const float bs = bias ? bias[c] : 0.0f;
-        // tap t = 3 ky + kx; py = 0: ky = 1 at row a; py = 1: ky = 2 at row a and ky = 0 at row a + 1 (same for columns)
-        const float o00 = bs + p00[12 + c];
-        const float o01 = bs + p00[15 + c] + p01[9 + c];
-        const float o10 = bs + p00[21 + c] + p10[3 + c];
-        const float o11 = bs + p00[24 + c] + p01[18 + c] + p10[6 + c] + p11[c];
+        const float o00 = bs + self[c];
+        const float o01 = bs + self[3 + c] + left[c];
+        const float o10 = bs + self[6 + c] + up[c];
+        const float o11 = bs + self[9 + c] + left[3 + c] + up[3 + c] + diag[c];
         if (u8) {
             orow[2 * la][(2 * lb) * cout + c] = clip_u8(o00 * 255.0f);
             orow[2 * la][(2 * lb + 1) * cout + c] = clip_u8(o01 * 255.0f);
