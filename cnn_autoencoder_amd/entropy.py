@@ -127,6 +127,46 @@ def _likelihood(params, n_filters: int, inputs: torch.Tensor, form: str = 'plain
     return likelihood, lower, upper
 
 
+class _DensityTrainFn(torch.autograd.Function):
+    """y (N, C, ...) + noise -> (y~, max(p(y~), bound)) with hand-written forward and backward kernels
+    (csrc/cae_density_train.hip; reference: compressai EntropyBottleneck.forward(training=True), _autoencoders.py:502).
+    `params`: matrices 0..K, biases 0..K, factors 0..K-1 in their stored form; gradients come back for each of them."""
+
+    @staticmethod
+    def forward(ctx, y, noise, plain, bound, *params):
+        L = _lib.lib()
+        y = y.contiguous().float()
+        n, c = y.size(0), y.size(1)
+        hw = y.numel() // (n * c)
+        raw = torch.cat([p.detach().reshape(c, -1).float() for p in params], dim=1).contiguous()
+        out, lik = torch.empty_like(y), torch.empty_like(y)
+        noise_c = None if noise is None else noise.to(y).contiguous()
+        _lib.check(L.cae_t_density_forward(y.data_ptr(), None if noise_c is None else noise_c.data_ptr(), raw.data_ptr(),
+                                           n, c, hw, int(plain), float(bound), out.data_ptr(), lik.data_ptr(),
+                                           _lib.stream_ptr()))
+        ctx.save_for_backward(out, raw)
+        ctx.meta = (n, c, hw, int(plain), float(bound), [tuple(p.shape) for p in params])
+        return out, lik
+
+    @staticmethod
+    def backward(ctx, g_out, g_lik):
+        L = _lib.lib()
+        out, raw = ctx.saved_tensors
+        n, c, hw, plain, bound, shapes = ctx.meta
+        g_lik = torch.zeros_like(out) if g_lik is None else g_lik.contiguous().float()
+        g_out_c = None if g_out is None else g_out.contiguous().float()
+        g_y, g_raw = torch.empty_like(out), torch.empty_like(raw)
+        _lib.check(L.cae_t_density_backward(out.data_ptr(), g_lik.data_ptr(), None if g_out_c is None else g_out_c.data_ptr(),
+                                            raw.data_ptr(), n, c, hw, plain, bound, g_y.data_ptr(), g_raw.data_ptr(),
+                                            _lib.stream_ptr()))
+        grads, col = [], 0
+        for shp in shapes:  # views into the (C, NP) gradient block
+            k = int(np.prod(shp[1:]))
+            grads.append(g_raw[:, col:col + k].reshape(shp))
+            col += k
+        return (g_y, None, None, None, *grads)
+
+
 class EntropyBottleneck(nn.Module):
     def __init__(self, channels: int, *args, tail_mass: float = 1e-9, init_scale: float = 10,
                  filters: Sequence[int] = (3, 3, 3, 3), likelihood_bound: float = 1e-9,
@@ -196,6 +236,21 @@ class EntropyBottleneck(nn.Module):
             out[k] = v.cpu().float() if cpu else v
         return out
 
+    def _bound_value(self) -> float:
+        """the likelihood bound as a host number, read once (a device read per step would synchronise the stream)"""
+        v = getattr(self, '_bound_host', None)
+        if v is None:
+            v = self._bound_host = float(self.likelihood_lower_bound.bound.item())
+        return v
+
+    def _fused_train(self) -> bool:
+        """fused training-mode density kernels (filters all equal to the built width; CAE_EB_FUSED=0 keeps the
+        element-wise graph, which the tests use as the comparison)"""
+        import os
+        if os.environ.get('CAE_EB_FUSED', '1') == '0' or len(set(self.filters)) != 1:
+            return False
+        return _lib.lib().cae_t_density_params(self.filters[0], len(self.filters)) > 0
+
     def _likelihood(self, inputs: torch.Tensor, stop_gradient: bool = False):
         return _likelihood(self._params(stop_gradient), len(self.filters), inputs, self.likelihood_form)
 
@@ -204,6 +259,15 @@ class EntropyBottleneck(nn.Module):
             training = self.training
         if not training and x.is_cuda and not torch.is_grad_enabled():
             return self._forward_hip(x)  # eval, no autograd: fused HIP kernel (cae_likelihood)
+        if training and x.is_cuda and self._fused_train():
+            # train mode on the GPU: one forward and one backward kernel instead of ~250 element-wise launches per step
+            fixed = getattr(self, 'fixed_noise', None)
+            noise = fixed if fixed is not None else torch.empty_like(x, dtype=torch.float32).uniform_(-0.5, 0.5)
+            k = len(self.filters)
+            params = ([getattr(self, f'_matrix{i:d}') for i in range(k + 1)] + [getattr(self, f'_bias{i:d}') for i in range(k + 1)]
+                      + [getattr(self, f'_factor{i:d}') for i in range(k)])
+            bound = self._bound_value() if self.use_likelihood_bound else 0.0
+            return _DensityTrainFn.apply(x, noise, self.likelihood_form == 'plain', bound, *params)
         perm = list(range(x.dim()))
         perm[0], perm[1] = 1, 0
         x = x.permute(*perm).contiguous()

@@ -287,6 +287,19 @@ int cae_t_gdn_backward(const float *z32, const float *gext32, int n, int h, int 
 int cae_t_fold_to_bf16(const float *gext32, int n, int h, int w, int pad, int cp, void *out16, void *stream);
 int cae_t_colsum(const void *g16, long pixels, int cp, float *out, void *stream); /* bias gradient */
 
+/* Training-mode density of the entropy bottleneck, fused (csrc/cae_density_train.hip).  Replaces the element-wise graph of
+ * compressai's EntropyBottleneck.forward(training=True) / _likelihood / LowerBound under autograd
+ * (_autoencoders.py:502 via models/tasks/_taskutils.py:95-108).
+ * raw_params: (channels, NP) fp32 = per channel [matrices 0..K | biases 0..K | factors 0..K-1], each in its stored
+ * (un-transformed) form and row-major shape; NP = cae_t_density_params(D, K) (0: shape not built; built: D = 3, K = 4).
+ * forward: out = y + noise (noise may be NULL), lik = max(p(out), bound); plain = 1: sigmoid(u) - sigmoid(l), 0: sign trick.
+ * backward: g_y = g_out (may be NULL) + g_lik dp/dy with the LowerBound rule; g_raw_params (channels, NP), overwritten. */
+int cae_t_density_params(int filters_d, int n_filters);
+int cae_t_density_forward(const float *y, const float *noise, const float *raw_params, int n, int channels, int hw, int plain,
+                          float bound, float *out, float *lik, void *stream);
+int cae_t_density_backward(const float *out, const float *g_lik, const float *g_out, const float *raw_params, int n,
+                           int channels, int hw, int plain, float bound, float *g_y, float *g_raw_params, void *stream);
+
 /* ---- host entropy coding ---------------------------------------------------------------
  * Replace compressai._CXX.pmf_to_quantized_cdf and compressai.ans.RansEncoder /
  * RansDecoder (encode_with_indexes / decode_with_indexes), reached from

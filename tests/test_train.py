@@ -313,3 +313,48 @@ def test_graphed_train_step_equals_the_eager_step(cae):
     assert rel(runs['graph'][1], runs['eager'][1]) < 1e-5 and rel(runs['graph'][2], runs['eager'][2]) < 1e-5
     with pytest.raises(ValueError):
         train.GraphedTrainStep(xs[0], model, criterion, train.setup_optim(model))  # optimisers not capturable
+
+
+@pytest.mark.parametrize('form', ['plain', 'sign_trick'])
+def test_fused_density_kernels_match_the_elementwise_graph(cae, form, monkeypatch):
+    """cae_t_density_forward / backward (train-mode EntropyBottleneck on the GPU) against the element-wise torch graph of
+    the same module (CAE_EB_FUSED=0) and the CPU restatement: outputs, likelihoods (incl. elements clamped at the 1e-9
+    bound, where the LowerBound rule decides the gradient), gradient with respect to the input and to every parameter."""
+    from oracle import train_oracle as T
+    torch.manual_seed(11)
+    c = 40
+    eb = cae.EntropyBottleneck(c, likelihood_form=form).cuda().train()
+    with torch.no_grad():
+        for name, p in eb.named_parameters():
+            if 'factor' in name:
+                p.copy_(0.3 * torch.randn_like(p))
+            elif 'matrix' in name:
+                p.add_(0.2 * torch.randn_like(p))
+    y = (torch.randn(3, c, 9, 7) * 4).cuda()
+    y[0, :, 0, 0] = 300.0  # far tail: p < 1e-9, clamped
+    y[1, :, 1, 1] = -300.0
+    noise = (torch.rand(3, c, 9, 7) - 0.5).cuda()
+    eb.fixed_noise = noise
+    w_out, w_lik = torch.randn(3, c, 9, 7).cuda(), torch.randn(3, c, 9, 7).cuda()
+
+    def run(fused):
+        monkeypatch.setenv('CAE_EB_FUSED', '1' if fused else '0')
+        yy = y.clone().requires_grad_(True)
+        eb.zero_grad()
+        out, lik = eb(yy)
+        ((out * w_out).sum() + (torch.log2(lik) * w_lik).sum()).backward()
+        return out.detach(), lik.detach(), yy.grad.clone(), {k: v.grad.clone() for k, v in eb.named_parameters() if v.grad is not None}
+
+    o1, l1, gy1, gp1 = run(True)
+    o0, l0, gy0, gp0 = run(False)
+    assert torch.equal(o1, o0)
+    np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=2e-5, atol=1e-12)
+    assert float((l1 == 1e-9).float().mean()) > 0.005  # the clamped elements are there
+    assert rel(gy1.cpu(), gy0.cpu()) < 1e-4
+    assert set(gp1) == set(gp0) and 'quantiles' not in gp1
+    for k in gp0:
+        assert rel(gp1[k].cpu(), gp0[k].cpu()) < 1e-4, k
+    # and the CPU restatement (forward)
+    params = {k: v.detach().cpu() for k, v in eb.named_parameters()}
+    _, lik_ref = T.entropy_forward(params, y.cpu(), noise.cpu(), len(eb.filters), form=form)
+    np.testing.assert_allclose(l1.cpu().numpy(), lik_ref.numpy(), rtol=1e-4, atol=1e-12)

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_train.py -x -q -k "graphed or twenty" < /dev/null > gpurun_out/graph_test.log 2>&1; rc=$?
+timeout -k 10 600 python -m pytest tests/test_train.py tests/test_dist.py -x -q < /dev/null > gpurun_out/graph_test.log 2>&1; rc=$?
 tail -40 gpurun_out/graph_test.log
 if grep -q "Memory access fault" gpurun_out/graph_test.log; then exit 9; fi
 [ $rc = 0 ] || exit $rc
