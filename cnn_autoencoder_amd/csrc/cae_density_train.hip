@@ -213,6 +213,23 @@ __global__ void __launch_bounds__(256) density_bwd_kernel(const float *vout, con
     }
 }
 
+// NonNegativeParametrizer of the GDN parameters (compressai.ops.parametrizers) as one kernel each way:
+// out = max(x, bound)^2 - pedestal;  g_x = g 2 max(x, bound) where x >= bound or that product is negative (LowerBound rule)
+__global__ void reparam_fwd_kernel(const float *x, long n, float bound, float pedestal, float *out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float c = fmaxf(x[i], bound);
+        out[i] = c * c - pedestal;
+    }
+}
+
+__global__ void reparam_bwd_kernel(const float *x, const float *g, long n, float bound, float *gx) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float xv = x[i], c = fmaxf(xv, bound);
+        const float gi = g[i] * (2.0f * c);  // gradient arriving at the LowerBound
+        gx[i] = (xv >= bound || gi < 0.0f) ? gi : 0.0f;
+    }
+}
+
 unsigned blocks_per_channel(long elems) {
     return (unsigned)std::min<long>(std::max<long>((elems + 2047) / 2048, 1), 32);
 }
@@ -243,6 +260,22 @@ int cae_t_density_backward(const float *out, const float *g_lik, const float *g_
     HIP_TRY(hipMemsetAsync(g_raw_params, 0, (size_t)channels * Lay<3, 4>::NP * sizeof(float), (hipStream_t)stream));
     hipLaunchKernelGGL((density_bwd_kernel<3, 4>), dim3(channels, blocks_per_channel((long)n * hw)), dim3(256), 0,
                        (hipStream_t)stream, out, g_lik, g_out, raw_params, n, channels, hw, plain, bound, g_y, g_raw_params);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_t_reparam_forward(const float *x, long n, float bound, float pedestal, float *out, void *stream) {
+    if (!x || !out || n < 1) return fail(CAE_ERR_ARG, "bad argument");
+    const unsigned grid = (unsigned)std::min<long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, bound, pedestal, out);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_t_reparam_backward(const float *x, const float *g, long n, float bound, float *gx, void *stream) {
+    if (!x || !g || !gx || n < 1) return fail(CAE_ERR_ARG, "bad argument");
+    const unsigned grid = (unsigned)std::min<long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, g, n, bound, gx);
     HIP_TRY(hipGetLastError());
     return CAE_OK;
 }

@@ -52,6 +52,30 @@ class RangeTicket:
             L.cae_thread_force_fp32(0)
 
 
+class _ReparamFn(torch.autograd.Function):
+    """max(x, bound)^2 - pedestal with the LowerBound gradient rule, one kernel each way (cae_t_reparam_*): as torch ops
+    the twelve GDN parameters of the canonical model cost ~120 launches per training step."""
+
+    @staticmethod
+    def forward(ctx, x, bound, pedestal):
+        xc = x.detach().contiguous().float()
+        out = torch.empty_like(xc)
+        _lib.check(_lib.lib().cae_t_reparam_forward(xc.data_ptr(), xc.numel(), bound, pedestal, out.data_ptr(),
+                                                    _lib.stream_ptr()))
+        ctx.save_for_backward(xc)
+        ctx.bound = bound
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        gx = torch.empty_like(xc)
+        _lib.check(_lib.lib().cae_t_reparam_backward(xc.data_ptr(), g.data_ptr(), xc.numel(), ctx.bound, gx.data_ptr(),
+                                                     _lib.stream_ptr()))
+        return gx, None, None
+
+
 class NonNegativeParametrizer(nn.Module):
     """compressai.ops.parametrizers.NonNegativeParametrizer."""
 
@@ -68,6 +92,11 @@ class NonNegativeParametrizer(nn.Module):
         return torch.sqrt(torch.max(x + self.pedestal, self.pedestal))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        import os
+        if (x.is_cuda and x.requires_grad and torch.is_grad_enabled()
+                and os.environ.get('CAE_REPARAM_FUSED', '1') != '0'):  # training on the GPU: fused kernels
+            bound = (self.minimum + self.reparam_offset ** 2) ** 0.5
+            return _ReparamFn.apply(x, float(np.float32(bound)), float(np.float32(self.reparam_offset ** 2)))
         out = self.lower_bound(x)
         return out ** 2 - self.pedestal
 

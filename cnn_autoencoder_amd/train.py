@@ -27,6 +27,8 @@ from __future__ import annotations
 import ctypes
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -460,6 +462,12 @@ class GraphedTrainStep:
             opt.zero_grad(set_to_none=False)  # the .grad buffers are part of the graphs
 
     def __call__(self, x: torch.Tensor):
+        # ONE step in flight: with the host free to queue replays ahead of the device (40 steps of 8 ms queued at once)
+        # training diverged on this ROCm build -- loss 336 instead of 69 after 43 steps -- and matched the eager step again
+        # with the stream drained before each step (tools/bench_train.py, profiles/r02_experiments.md 13).  Nothing of
+        # this package runs during a replay, so the hazard is below it; the eager train_step is the recommended (and, with
+        # the fused density / reparametrisation kernels, the faster) path.
+        torch.cuda.current_stream().synchronize()
         self.x.copy_(x, non_blocking=True)
         self.g_fb.replay()
         if self.reducer is not None:

@@ -299,6 +299,10 @@ int cae_t_density_forward(const float *y, const float *noise, const float *raw_p
                           float bound, float *out, float *lik, void *stream);
 int cae_t_density_backward(const float *out, const float *g_lik, const float *g_out, const float *raw_params, int n,
                            int channels, int hw, int plain, float bound, float *g_y, float *g_raw_params, void *stream);
+/* compressai NonNegativeParametrizer (GDN beta / gamma; layers/gdn.py via _autoencoders.py GDN units) under autograd:
+ * out = max(x, bound)^2 - pedestal;  g_x = g 2 max(x, bound) where x >= bound or that value is negative (LowerBound rule). */
+int cae_t_reparam_forward(const float *x, long n, float bound, float pedestal, float *out, void *stream);
+int cae_t_reparam_backward(const float *x, const float *g, long n, float bound, float *gx, void *stream);
 
 /* ---- host entropy coding ---------------------------------------------------------------
  * Replace compressai._CXX.pmf_to_quantized_cdf and compressai.ans.RansEncoder /

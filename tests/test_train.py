@@ -358,3 +358,23 @@ def test_fused_density_kernels_match_the_elementwise_graph(cae, form, monkeypatc
     params = {k: v.detach().cpu() for k, v in eb.named_parameters()}
     _, lik_ref = T.entropy_forward(params, y.cpu(), noise.cpu(), len(eb.filters), form=form)
     np.testing.assert_allclose(l1.cpu().numpy(), lik_ref.numpy(), rtol=1e-4, atol=1e-12)
+
+
+def test_fused_reparametrisation_matches_the_torch_ops(cae):
+    """NonNegativeParametrizer under autograd on the GPU (cae_t_reparam_*: one kernel each way) against its torch-op form
+    on the CPU: values and the LowerBound gradient rule (elements below the bound pass only negative gradients)."""
+    from cnn_autoencoder_amd.modules import NonNegativeParametrizer
+    torch.manual_seed(2)
+    for minimum in (0.0, 1e-6):
+        rp = NonNegativeParametrizer(minimum=minimum)
+        bound = float(rp.lower_bound.bound)
+        x = torch.cat([torch.rand(500) * 0.2, torch.full((20,), bound * 0.5), torch.tensor([bound, -1.0])])
+        w = torch.randn_like(x)
+        x_cpu = x.clone().requires_grad_(True)
+        (rp(x_cpu) * w).sum().backward()
+        x_gpu = x.cuda().requires_grad_(True)
+        out = rp.cuda()(x_gpu)
+        (out * w.cuda()).sum().backward()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), rp.cpu()(x).numpy(), rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(x_gpu.grad.cpu().numpy(), x_cpu.grad.numpy(), rtol=1e-6, atol=1e-12)
+        assert float((x_cpu.grad == 0).float().mean()) > 0.005  # blocked gradients are part of the case

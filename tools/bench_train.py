@@ -14,13 +14,29 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 patch = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 model = cae.autoencoder_from_state_dict(synth.synthetic_state(dict(synth.CANONICAL), seed=0), train=True)
 mode = sys.argv[4] if len(sys.argv) > 4 else 'graph'
-opts = train.setup_optim(model, capturable=mode == 'graph')
+opts = train.setup_optim(model, capturable=mode == 'graph' or os.environ.get('CAE_BENCH_CAPTURABLE') == '1')
 criterion = criteria.GeneralLoss(distortion_lambda=0.01)
 x = torch.rand(batch, 3, patch, patch, device='cuda')
 if mode == 'graph':
     step = train.GraphedTrainStep(x, model, criterion, opts, warmup=3)
 else:
-    step = lambda t: train.train_step(t, model, criterion, opts)  # noqa: E731
+    if os.environ.get('CAE_BENCH_KEEPGRADS') == '1':  # eager, but with the persistent .grad buffers of the graphed step
+        from cnn_autoencoder_amd.criteria import setup_forward_func
+        ff = setup_forward_func()
+
+        def step(t):
+            out = ff(t, model)
+            ld = criterion(inputs=t, outputs=out, net=model)
+            torch.mean(ld['loss']).backward()
+            if 'entropy_loss' in ld:
+                torch.mean(ld['entropy_loss']).backward()
+            for opt in opts.values():
+                torch.nn.utils.clip_grad_norm_(opt.param_groups[0]['params'], max_norm=1.0)
+                opt.step()
+                opt.zero_grad(set_to_none=False)
+            return ld
+    else:
+        step = lambda t: train.train_step(t, model, criterion, opts)  # noqa: E731
 for _ in range(3):
     step(x)
 torch.cuda.synchronize()
