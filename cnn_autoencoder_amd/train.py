@@ -408,18 +408,19 @@ def train_step(x: torch.Tensor, model, criterion, optimizers, forward_func=None,
 
 
 class GraphedTrainStep:
-    """train_step replayed from HIP graphs.  One iteration of the reference's loop is ~600 kernel launches of a few
-    microseconds each (the entropy model's density, the losses, clipping and four Adam instances are element-wise
-    torch ops): launched one by one the GPU idles about half of the step.  Captured once --
+    """train_step replayed from HIP graphs --
 
       graph 1: forward_func -> criterion -> backward -> aux-loss backward        (gradients land in static .grad buffers)
       [reducer.reduce(): the bucketed all-reduce stays outside, RCCL picks its own launch order]
       graph 2: clip_grad_norm_(1.0) -> step -> zero_grad per optimiser
 
-    -- a step is a copy of the batch into the static input and two replays.  Same arithmetic as train_step; the uniform
-    noise of the entropy bottleneck is drawn inside the graph (the generator's offset advances per replay).  Needs
-    optimisers built with setup_optim(capturable=True), a fixed batch shape, and `warmup` ordinary steps first (they are
-    real training steps: lazy initialisation and the optimiser state must exist before capture).
+    -- a step is a copy of the batch into the static input and two replays.  Same arithmetic as train_step (equal step for
+    step, tests/test_train.py); the uniform noise of the entropy bottleneck is drawn inside the graph.  Measured: NOT
+    faster than the eager step (7.8 vs 7.4 ms at 16 x 256^2: the kernels of a step are strictly dependent and the gap
+    between two dependent dispatches is the same from a graph), and replays must not run ahead of the device on this ROCm
+    build (see __call__).  Kept as an option; train_step is the recommended loop.
+    Needs optimisers built with setup_optim(capturable=True), a fixed batch shape, and `warmup` ordinary steps first (they
+    are real training steps: lazy initialisation and the optimiser state must exist before capture).
     The returned loss_dict holds STATIC tensors: read them before the next call."""
 
     def __init__(self, x_example: torch.Tensor, model, criterion, optimizers, forward_func=None,

@@ -7,6 +7,7 @@ HEAD=$(git rev-parse --short HEAD)
 cp $O/bench_f16x3.json profiles/r02_bench_f16x3.json
 cp $O/stats/p_kernel_stats.csv profiles/r02_f16x3_kernel_stats.csv
 cp $O/pmc_busy.txt profiles/r02_f16x3_pmc_busy.txt
+[ -f $O/train_stats/p_kernel_stats.csv ] && cp $O/train_stats/p_kernel_stats.csv profiles/r02_train_kernel_stats.csv
 python3 tools/gpu_idle.py $O/stats > profiles/r02_f16x3_gpu_idle.txt
 python3 tools/hbm_traffic.py $O/fetch $O/write > /tmp/hbm_r02.json
 python3 - <<PY
