@@ -374,8 +374,8 @@ def setup_optim(model: Dict[str, nn.Module], trainable_modules: Sequence[str] = 
                 learning_rate: float = 1e-4, aux_learning_rate: float = 1e-3, weight_decay: float = 0.0,
                 algo=torch.optim.Adam, capturable: bool = False) -> Dict[str, torch.optim.Optimizer]:
     """One optimiser per trainable module; parameters whose name contains 'quantiles' or 'aux' go to a separate
-    ``<module>_aux`` optimiser (train_cae_ms.py:584-641).  capturable: step counters on the device, as
-    GraphedTrainStep needs them."""
+    ``<module>_aux`` optimiser (train_cae_ms.py:584-641).  capturable: step counters on the device (no host read per
+    step)."""
     opts: Dict[str, torch.optim.Optimizer] = {}
     extra = dict(capturable=True) if capturable else {}
     for k in trainable_modules:
@@ -405,76 +405,6 @@ def train_step(x: torch.Tensor, model, criterion, optimizers, forward_func=None,
         opt.step()
         opt.zero_grad()
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
-
-
-class GraphedTrainStep:
-    """train_step replayed from HIP graphs --
-
-      graph 1: forward_func -> criterion -> backward -> aux-loss backward        (gradients land in static .grad buffers)
-      [reducer.reduce(): the bucketed all-reduce stays outside, RCCL picks its own launch order]
-      graph 2: clip_grad_norm_(1.0) -> step -> zero_grad per optimiser
-
-    -- a step is a copy of the batch into the static input and two replays.  Same arithmetic as train_step (equal step for
-    step, tests/test_train.py); the uniform noise of the entropy bottleneck is drawn inside the graph.  Measured: NOT
-    faster than the eager step (7.8 vs 7.4 ms at 16 x 256^2: the kernels of a step are strictly dependent and the gap
-    between two dependent dispatches is the same from a graph), and replays must not run ahead of the device on this ROCm
-    build (see __call__).  Kept as an option; train_step is the recommended loop.
-    Needs optimisers built with setup_optim(capturable=True), a fixed batch shape, and `warmup` ordinary steps first (they
-    are real training steps: lazy initialisation and the optimiser state must exist before capture).
-    The returned loss_dict holds STATIC tensors: read them before the next call."""
-
-    def __init__(self, x_example: torch.Tensor, model, criterion, optimizers, forward_func=None,
-                 reducer: 'GradReducer' = None, warmup: int = 3):
-        from .criteria import setup_forward_func
-        self.model, self.criterion, self.optimizers, self.reducer = model, criterion, optimizers, reducer
-        self.forward_func = forward_func or setup_forward_func()
-        self.x = x_example.detach().clone()
-        for opt in optimizers.values():
-            if not opt.defaults.get('capturable', False):
-                raise ValueError('GraphedTrainStep needs optimisers built with capturable=True (setup_optim(capturable=True))')
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):
-                self._forward_backward()
-                if reducer is not None:
-                    reducer.reduce()
-                self._update()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.g_fb, self.g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
-            self.loss_dict = self._forward_backward()
-        with torch.cuda.graph(self.g_up, pool=self.g_fb.pool()):
-            self._update()
-
-    def _forward_backward(self):
-        output = self.forward_func(self.x, self.model)
-        loss_dict = self.criterion(inputs=self.x, outputs=output, net=self.model)
-        torch.mean(loss_dict['loss']).backward()
-        if 'entropy_loss' in loss_dict:
-            torch.mean(loss_dict['entropy_loss']).backward()
-        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
-
-    def _update(self):
-        for opt in self.optimizers.values():
-            nn.utils.clip_grad_norm_(opt.param_groups[0]['params'], max_norm=1.0)
-            opt.step()
-            opt.zero_grad(set_to_none=False)  # the .grad buffers are part of the graphs
-
-    def __call__(self, x: torch.Tensor):
-        # ONE step in flight: with the host free to queue replays ahead of the device (40 steps of 8 ms queued at once)
-        # training diverged on this ROCm build -- loss 336 instead of 69 after 43 steps -- and matched the eager step again
-        # with the stream drained before each step (tools/bench_train.py, profiles/r02_experiments.md 13).  Nothing of
-        # this package runs during a replay, so the hazard is below it; the eager train_step is the recommended (and, with
-        # the fused density / reparametrisation kernels, the faster) path.
-        torch.cuda.current_stream().synchronize()
-        self.x.copy_(x, non_blocking=True)
-        self.g_fb.replay()
-        if self.reducer is not None:
-            self.reducer.reduce()
-        self.g_up.replay()
-        return self.loss_dict
 
 
 class GradReducer:

@@ -282,39 +282,6 @@ def test_twenty_training_steps_follow_the_restatement(cae):
     assert rel(eb.quantiles.detach().cpu(), eb_ref['quantiles'].detach()) < 1e-3
 
 
-def test_graphed_train_step_equals_the_eager_step(cae):
-    """train.GraphedTrainStep (forward + losses + backward in one HIP graph, clipping + Adam in a second) against
-    train.train_step on an identical copy of the model: same batches, same (fixed) bottleneck noise -> the same loss
-    curve and the same parameters; warm-up steps are ordinary training steps on the example batch."""
-    from cnn_autoencoder_amd import criteria, synth, train
-    cfg = dict(synth.CANONICAL, channels_net=32, channels_bn=48, compression_level=3)
-    gen = torch.Generator().manual_seed(9)
-    xs = [torch.rand(4, 3, 48, 64, generator=gen).cuda() for _ in range(5)]
-    noise = (torch.rand(4, 48, 6, 8, generator=gen) - 0.5).cuda()
-    runs = {}
-    for mode in ('eager', 'graph'):
-        model = cae.autoencoder_from_state_dict(synth.synthetic_state(cfg, seed=31), train=True)
-        model['fact_ent'].module.fixed_noise = noise
-        criterion = criteria.GeneralLoss(distortion_lambda=0.01)
-        opts = train.setup_optim(model, learning_rate=1e-3, aux_learning_rate=1e-2, capturable=True)
-        losses = []
-        if mode == 'eager':
-            for x in [xs[0], xs[0]] + xs[1:]:
-                losses.append(float(train.train_step(x, model, criterion, opts)['loss']))
-            losses = losses[2:]
-        else:
-            step = train.GraphedTrainStep(xs[0], model, criterion, opts, warmup=2)
-            for x in xs[1:]:
-                losses.append(float(step(x)['loss']))
-        w = model['encoder'].module.analysis_track[0].model[0].weight.detach().cpu().clone()
-        q = model['fact_ent'].module.quantiles.detach().cpu().clone()
-        runs[mode] = (losses, w, q)
-    np.testing.assert_allclose(runs['graph'][0], runs['eager'][0], rtol=1e-5)
-    assert rel(runs['graph'][1], runs['eager'][1]) < 1e-5 and rel(runs['graph'][2], runs['eager'][2]) < 1e-5
-    with pytest.raises(ValueError):
-        train.GraphedTrainStep(xs[0], model, criterion, train.setup_optim(model))  # optimisers not capturable
-
-
 @pytest.mark.parametrize('form', ['plain', 'sign_trick'])
 def test_fused_density_kernels_match_the_elementwise_graph(cae, form, monkeypatch):
     """cae_t_density_forward / backward (train-mode EntropyBottleneck on the GPU) against the element-wise torch graph of

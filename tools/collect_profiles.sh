@@ -20,7 +20,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o p -
 echo "write done" >> $O/progress.txt
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/busy -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-sub-runs > /dev/null 2> $O/busy.err < /dev/null
 echo "busy done" >> $O/progress.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -o p -- python3 $R/tools/bench_train.py 16 20 256 eager > $O/train_bench.json 2> $O/train_stats.err < /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -o p -- python3 $R/tools/bench_train.py 16 20 256 > $O/train_bench.json 2> $O/train_stats.err < /dev/null
 echo "train stats done" >> $O/progress.txt
 cd $R
 python3 tools/summarize_trace.py $(ls $O/stats/*kernel_trace.csv | head -1) 1 > $O/kernel_summary.md 2> $O/summ.err < /dev/null
