@@ -261,6 +261,22 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[CT], const Layer
 #ifndef CAE_CONV_WAVES
 #define CAE_CONV_WAVES 2
 #endif
+// XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8 XCDs, each with a private L2, so
+// neighbouring tiles -- which share halo rows / columns and re-read them per kernel-row stage -- land on different L2s.
+// Give every XCD a contiguous range of tiles instead (whole images at bench sizes).  Bijective for any grid size; a
+// placement guess that only affects speed (the block -> XCD map is not a contract).
+#ifndef CAE_XCD_SWIZZLE
+#define CAE_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ int xcd_tile_order(int bid, int nwg) {
+#if CAE_XCD_SWIZZLE
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+#else
+    return bid;
+#endif
+}
+
 // S = stride (2: DownsamplingUnit's strided conv; 1: the pre-activation conv of the LeakyReLU/ReLU units,
 // _autoencoders.py:62-70, and -- with ZEROPAD and flipped weights -- ConvTranspose2d(stride 1), :187-196)
 template <int KS, int CT, int NW, bool GDN, int S = 2, bool ZEROPAD = false, bool INV = false>
@@ -282,7 +298,7 @@ __global__ void __launch_bounds__(NW * 64, (GDN && CT >= 6) ? 1 : (CT <= 4 ? CAE
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, m = lane & 31;
 
-    int bid = blockIdx.x;
+    int bid = xcd_tile_order(blockIdx.x, gridDim.x);
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
@@ -545,7 +561,7 @@ __global__ void __launch_bounds__(NW * 64, CT >= 6 ? 1 : 2) deconv_s2_kernel(con
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, m = lane & 31;
 
-    int bid = blockIdx.x;
+    int bid = xcd_tile_order(blockIdx.x, gridDim.x);
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;

@@ -41,21 +41,6 @@ namespace cae {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-// XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8 XCDs, each with a private L2, so
-// neighbouring tiles -- which share halo rows / columns and re-read them per kernel-row stage -- land on different L2s.
-// Give every XCD a contiguous range of tiles instead (whole images at bench sizes).  Bijective for any grid size; a
-// placement guess that only affects speed (the block -> XCD map is not a contract).
-#ifndef CAE_XCD_SWIZZLE
-#define CAE_XCD_SWIZZLE 1
-#endif
-__device__ __forceinline__ int xcd_tile_order(int bid, int nwg) {
-#if CAE_XCD_SWIZZLE
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-#else
-    return bid;
-#endif
-}
 
 __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
