@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU: random model shapes (channels, kernel size, depth, bias, activation variant,
 residual, batch norm, expansion) and tile sizes against the CPU oracle / torch-CPU replay of the folded layers.
-usage: fuzz_parity.py [n_cases] [seed]   -> prints failures, exits 1 if any."""
+usage: fuzz_parity.py [n_cases] [seed] [first_case]   -> prints failures, exits 1 if any.
+(first_case > 0: the earlier cases only advance the generator; every case is then announced before it touches the GPU, so a
+faulting one can be named from the log)"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +15,7 @@ from test_host import cpu_track
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+first_case = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 fails = skipped = 0
 t_start = time.time()
 for case in range(n_cases):
@@ -44,16 +47,28 @@ for case in range(n_cases):
     prec = str(rng.choice(['fp32', 'f16x3']))
     enc.precision = dec.precision = prec
     tiles = rng.integers(0, 256, (n, h, w, kw['channels_org']), dtype=np.uint8)
+    if case < first_case:
+        continue
+    if first_case:
+        print('case', case, prec, kw, (n, h, w), flush=True)
     x = torch.from_numpy(tiles).permute(0, 3, 1, 2).float() / 255.0
     with torch.no_grad():
         y_ref, _ = cpu_track(enc.analysis_track, x, False)
         yq = torch.round(y_ref)
         xr_ref, _ = cpu_track(dec.synthesis_track, yq, True)
         try:
+            def mark(what):  # (first_case runs: name the call a fault belongs to)
+                if first_case:
+                    torch.cuda.synchronize()
+                    print('  ->', what, flush=True)
             enc.cuda(); dec.cuda()
+            mark('enc.forward_u8')
             y = enc.forward_u8(torch.from_numpy(tiles).cuda()).cpu()
+            mark('dec()')
             x_r, _ = dec(yq.cuda())
+            mark('dec.forward_u8')
             u8 = dec.forward_u8(yq.cuda()).cpu()  # codec path (k = 3 GDN models: product-map form of the last two layers)
+            mark('entropy model')
             # fused quantiser / dequantiser entry points == the unfused calls, bit for bit
             eb = cae.EntropyBottleneck(kw['channels_bn']).eval()
             with torch.no_grad():
@@ -61,9 +76,15 @@ for case in range(n_cases):
             eb.update(force=True)
             eb.cuda()
             td = torch.from_numpy(tiles).cuda()
+            mark('enc.forward_u8_symbols')
             sym = enc.forward_u8_symbols(td, eb)
+            mark('quantize_symbols(enc.forward_u8)')
             assert torch.equal(sym, eb.quantize_symbols(enc.forward_u8(td))), 'fused quantiser differs'
-            assert torch.equal(dec.forward_symbols_u8(sym, eb), dec.forward_u8(eb.dequantize_symbols(sym))), 'fused dequantiser differs'
+            mark('dec.forward_symbols_u8')
+            a8 = dec.forward_symbols_u8(sym, eb)
+            mark('dec.forward_u8(dequantize_symbols)')
+            assert torch.equal(a8, dec.forward_u8(eb.dequantize_symbols(sym))), 'fused dequantiser differs'
+            mark('done')
             enc.cpu(); dec.cpu()
         except Exception as e:
             fails += 1
