@@ -938,7 +938,9 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
     int *flag = f16 ? m->next_flag(&ticket) : m->flags_dev;
 
     // planes of the converted latents: padded so whole MFMA k-steps can be read (zero channels)
-    const int p0 = f16 ? 4 * ((m->c_bn + 31) / 32) : (m->c_bn + 7) / 8;
+    // (fp32: an EVEN number of 8-channel planes -- the last-layer kernel consumes 16-channel groups, and with one layer it
+    //  reads these planes directly: 72 latent channels = 9 planes made it read a tenth one past the buffer)
+    const int p0 = f16 ? 4 * ((m->c_bn + 31) / 32) : 2 * ((m->c_bn + 15) / 16);
     // f16x3: the synthesis track keeps its activations in C8SP rows (pitch = whole 64-pixel blocks)
     auto row_bytes = [&](int cw) { return f16 ? c8s_row_bytes<true>(cw) : (size_t)cw * 32; };
     size_t in_bytes = (size_t)n * p0 * lh * row_bytes(lw);

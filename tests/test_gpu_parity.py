@@ -617,3 +617,35 @@ def test_gdn_wider_than_128_channels_stays_on_f16x3(cae, ks, shape, monkeypatch)
         eff = ctypes.c_int(-1)
         _lib.check(_lib.lib().cae_model_effective_precision(tr._handle.ptr, ctypes.byref(eff)))
         assert eff.value == 1 and tr.fp32_fallbacks == 0
+
+
+def test_single_layer_fp32_synthesis_reads_only_its_own_planes(built_lib):
+    """Regression (randomised sweep, seed 312 case 342): with ONE synthesis layer the fp32 last-layer kernel reads the
+    converted latents directly, in 16-channel groups; 72 latent channels were 9 planes of 8 and the kernel read a tenth
+    past the buffer -- silent inside the allocator's slack, a GPU memory fault when the buffer ended on a mapping.  Run in
+    a child process with the fragment allocator off (every allocation its own mapping), against the CPU replay."""
+    import subprocess, sys, os, textwrap
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import cnn_autoencoder_amd as cae
+        from test_host import cpu_track
+        for bn in (72, 4):
+            kw = dict(channels_org=1, channels_net=64, channels_bn=bn, compression_level=1, kernel_size=5, bias=False,
+                      act_layer_type='LeakyReLU', batch_norm=False)
+            torch.manual_seed(bn)
+            dec = cae.Synthesizer(**kw).eval()
+            dec.precision = 'fp32'
+            yq = torch.round(torch.randn(3, bn, 26, 46) * 3)
+            with torch.no_grad():
+                ref, _ = cpu_track(dec.synthesis_track, yq, True)
+                out, _ = dec.cuda()(yq.cuda())
+            torch.cuda.synchronize()
+            err = float((out[0].cpu() - ref).abs().max() / max(1.0, float(ref.abs().max())))
+            assert err < 1e-4, (bn, err)
+        print('ok')
+    """) % (ROOT, os.path.join(ROOT, 'tests'))
+    env = dict(os.environ, HSA_DISABLE_FRAGMENT_ALLOCATOR='1', CAE_PRECISION='fp32')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ok' in r.stdout and 'Memory access fault' not in (r.stdout + r.stderr), r.stderr[-800:]
