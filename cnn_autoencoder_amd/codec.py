@@ -141,7 +141,30 @@ class ConvolutionalAutoencoder(_CodecBase):
         self.checkpoint = checkpoint
         self.gpu = gpu
         self._model = autoencoder_from_state_dict(checkpoint, gpu=gpu, train=False)
-        self._lock = threading.Lock()  # dask calls encode/decode from a thread pool (compress.py:121-128)
+        # dask calls encode / decode from a thread pool on this one instance (compress.py:121-128).  The lock covers
+        # the GPU section only (the tracks' workspaces are used in stream order); range coding runs outside it.
+        self._lock = threading.Lock()
+        self._door = None
+        self._door_mu = threading.Lock()
+
+    def _front_door(self):
+        """The micro-batching front door of encode() / decode() (frontdoor.FrontDoor), created on first use;
+        CAE_DOOR=0 keeps every call a batch of one."""
+        import os
+        if os.environ.get('CAE_DOOR', '1') == '0':
+            return None
+        if self._door is None:
+            with self._door_mu:
+                if self._door is None:
+                    from .frontdoor import FrontDoor
+                    self._door = FrontDoor(self)
+        return self._door
+
+    def close(self):
+        """Stops the front door's service threads (they are daemons: optional)."""
+        if self._door is not None:
+            self._door.close()
+            self._door = None
 
     # ---- batched side doors ------------------------------------------------------------------
     @torch.no_grad()
@@ -152,10 +175,12 @@ class ConvolutionalAutoencoder(_CodecBase):
             raise ValueError(f'expected uint8 (n,h,w,c), got {tiles.dtype} {tiles.shape}')
         n, h, w, _ = tiles.shape
         dev = _lib.require_gpu()
-        with self._lock:
+        eb = _module(self._model['fact_ent'])
+        with self._lock:  # GPU section: H2D, analysis with the fused quantiser, D2H of the symbols
             x = torch.from_numpy(tiles).to(dev)
-            y = _module(self._model['encoder']).forward_u8(x)
-            strings = _module(self._model['fact_ent']).compress(y)
+            sym = _module(self._model['encoder']).forward_u8_symbols(x, eb)
+            sym_host = sym.reshape(n, sym.size(1), -1).cpu().numpy()
+        strings = eb.encode_symbols(sym_host)  # host range coder: outside the lock
         head = struct.pack('>QQ', h, w)
         return [head + s for s in strings]
 
@@ -163,15 +188,18 @@ class ConvolutionalAutoencoder(_CodecBase):
     def decode_batch(self, bufs: Sequence[bytes]) -> np.ndarray:
         """chunk byte strings of equal tile size -> (n,h,w,c) uint8."""
         dec = _module(self._model['decoder'])
+        eb = _module(self._model['fact_ent'])
         level = len(dec.synthesis_track)
         hw = {struct.unpack('>QQ', bytes(b[:16])) for b in bufs}
         if len(hw) != 1:
             raise ValueError('decode_batch needs chunks of one tile size')
         h, w = hw.pop()
-        size = (h // 2 ** level, w // 2 ** level)
+        lh, lw = h // 2 ** level, w // 2 ** level
+        dev = _lib.require_gpu()
+        sym_host = eb.decode_symbols([bytes(b[16:]) for b in bufs], lh * lw)  # host range decoder: outside the lock
         with self._lock:
-            y_q = _module(self._model['fact_ent']).decompress([bytes(b[16:]) for b in bufs], size=size)
-            out = dec.forward_u8(y_q)
+            sym = torch.from_numpy(sym_host).to(dev).reshape(len(bufs), eb.channels, lh, lw)
+            out = dec.forward_symbols_u8(sym, eb)
             return out.cpu().numpy()
 
     # ---- numcodecs contract ----------------------------------------------------------------------
@@ -179,12 +207,21 @@ class ConvolutionalAutoencoder(_CodecBase):
         buf = np.asarray(buf)
         if buf.ndim != 3:
             raise ValueError(f'expected an (h,w,c) chunk, got shape {buf.shape}')
+        door = self._front_door()
+        if door is not None:
+            return door.encode(buf)
         return self.encode_batch(buf[None])[0]
 
     def decode(self, buf, out=None):
         if out is not None:
             out = ensure_contiguous_ndarray(out)
-        x_r = np.ascontiguousarray(self.decode_batch([bytes(buf)])[0])
+        door = self._front_door()
+        if door is not None:
+            x_r = door.decode(buf, out)
+            if x_r is out:
+                return out
+        else:
+            x_r = np.ascontiguousarray(self.decode_batch([bytes(buf)])[0])
         return ndarray_copy(ensure_contiguous_ndarray(x_r), out)
 
 
@@ -237,8 +274,10 @@ class ConvolutionalAutoencoderBottleneck(_CodecBase):
             raise ValueError(f'expected an (h,w,c) latent chunk, got shape {buf.shape}')
         h, w, c = buf.shape
         y = torch.from_numpy(buf).permute(2, 0, 1).reshape(1, c, h, w)
-        with self._lock:
-            s = self._fact_ent.compress(y)
+        with self._lock:  # GPU section (quantiser kernel); the range coder runs outside, in the caller's thread
+            sym = self._fact_ent.quantize_symbols(y)
+            sym_host = sym.reshape(1, c, -1).cpu().numpy()
+        s = self._fact_ent.encode_symbols(sym_host, threads=1)
         return struct.pack('>QQ', h, w) + s[0]
 
     @torch.no_grad()
@@ -247,9 +286,11 @@ class ConvolutionalAutoencoderBottleneck(_CodecBase):
             out = ensure_contiguous_ndarray(out)
         buf = bytes(buf)
         h, w = struct.unpack('>QQ', buf[:16])
+        sym_host = self._fact_ent.decode_symbols([buf[16:]], h * w, threads=1)  # range decoder: outside the lock
         with self._lock:
-            y_q = self._fact_ent.decompress([buf[16:]], size=(h, w))
-        y_q = np.ascontiguousarray(y_q[0].cpu().permute(1, 2, 0).float().numpy())
+            sym = torch.from_numpy(sym_host).reshape(1, self.channels_bn, h, w)
+            y_q = self._fact_ent.dequantize_symbols(sym).cpu()
+        y_q = np.ascontiguousarray(y_q[0].permute(1, 2, 0).float().numpy())
         return ndarray_copy(ensure_contiguous_ndarray(y_q), out)
 
 

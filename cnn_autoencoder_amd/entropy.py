@@ -10,6 +10,7 @@ fallback for the coding path).
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -18,6 +19,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+
+
+_SYNC_MU = threading.Lock()  # first use of a module's coder tables from several threads at once (codec front door)
 
 
 class _LowerBoundFn(torch.autograd.Function):
@@ -403,11 +407,14 @@ class EntropyBottleneck(nn.Module):
         if self._quantized_cdf.numel() == 0:
             raise ValueError('Uninitialized CDFs. Run update() first')
         ver = self.tables_version()
-        if self._handle is None:
-            self._handle = _lib.Handle(1, 1, self.channels, 1, 3)
-        if self._tables_version != ver:
-            self.upload_tables(self._handle)
-            self._tables_version = ver
+        if self._handle is not None and self._tables_version == ver:
+            return self._handle  # (the coder entry points are called from many threads at once: codec front door)
+        with _SYNC_MU:
+            if self._handle is None:
+                self._handle = _lib.Handle(1, 1, self.channels, 1, 3)
+            if self._tables_version != ver:
+                self.upload_tables(self._handle)
+                self._tables_version = ver
         return self._handle
 
     def tables_version(self):
