@@ -27,6 +27,10 @@ Objects in the line besides the driver's contract:
   cpu_baseline  the CPU oracle (torch-CPU conv + restated GDN + C rANS) on a bounded sample of the
                 same tiles on this host's cores -- a reported baseline, not the target
   parity_vs_cpu the GPU path against that oracle on the very same tiles: bpp, PSNR, bitstreams, pixels
+  dropin        (N=1) the reference's OWN call pattern: 1 / 8 / 16 Python threads calling codec.encode(chunk) /
+                codec.decode(buf) one 1024^2 chunk at a time on one shared codec (dask's threaded scheduler,
+                compress.py:121-128), host memory in, host memory out: tiles/s of each direction, next to the
+                pipelined SlideCoder number above (which codes AND decodes every tile)
 """
 import argparse
 import json
@@ -82,7 +86,7 @@ def oracle_layers(state, part, track):
 
 def cpu_baseline(state, cfg, tiles, budget_s=20.0):
     """Time the oracle's codec round trip, one tile per call (the reference's call pattern,
-    _autoencoders.py:544), on this host's cores.  -> (report, per-tile [bytes, sse], payloads, reconstructions)"""
+    _autoencoders.py:544), on this host's cores.  -> (report, per-tile [bytes, sse], payloads, reconstructions, latents)"""
     import struct
     from oracle import c_oracle as C
     from oracle import cae_oracle as O
@@ -101,7 +105,7 @@ def cpu_baseline(state, cfg, tiles, budget_s=20.0):
     done, t0 = 0, time.perf_counter()
     part = dict(analysis=0.0, entropy_encode=0.0, entropy_decode=0.0, synthesis=0.0)
     L = len(dec_l)
-    per_tile, payloads, recs = [], [], []
+    per_tile, payloads, recs, latents = [], [], [], []
     with torch.no_grad():
         for t in tiles:  # O.codec_encode / O.codec_decode, spelled out to time their parts
             h, w, _ = t.shape
@@ -121,6 +125,7 @@ def cpu_baseline(state, cfg, tiles, budget_s=20.0):
             per_tile.append((len(buf), float(((rec.astype(np.float64) - t) ** 2).sum())))
             payloads.append(buf[16:])
             recs.append(rec)
+            latents.append(y)
             if time.perf_counter() - t0 > budget_s:
                 break
     dt = time.perf_counter() - t0
@@ -128,7 +133,25 @@ def cpu_baseline(state, cfg, tiles, budget_s=20.0):
                   sample=f'{done} tiles of {tiles[0].shape[0]}x{tiles[0].shape[1]}x{tiles[0].shape[2]}, '
                          f'encode+decode one tile per call, {dt:.1f} s',
                   ms_per_tile={k: 1e3 * v / done for k, v in part.items()})
-    return report, per_tile, payloads, recs
+    return report, per_tile, payloads, recs, latents
+
+
+def flip_report(enc, eb, tiles_dev, y_cpu):
+    """The float -> integer cliff, characterised: symbols round(y - median) of the GPU latents against those of the
+    CPU oracle's own latents on the same tiles.  A flip is float noise if BOTH latents sit next to the rounding
+    boundary between the two symbols: `max_boundary_distance` = the largest such distance over all flips."""
+    y = enc.forward_u8(tiles_dev).cpu()
+    y_cpu = torch.cat(y_cpu)
+    m = eb._get_medians().detach().cpu().reshape(1, -1, 1, 1)
+    s_gpu, s_cpu = torch.round(y - m), torch.round(y_cpu - m)
+    flips = s_gpu != s_cpu
+    bound = torch.minimum(s_gpu, s_cpu) + 0.5
+    dist = torch.maximum((y - m - bound).abs(), (y_cpu - m - bound).abs())[flips]
+    return dict(symbols_flipped=int(flips.sum()), symbols_total=int(flips.numel()),
+                flipped_per_tile=[int(v) for v in flips.flatten(1).sum(1)],
+                max_symbol_delta=int((s_gpu - s_cpu).abs().max()),
+                max_boundary_distance=float(dist.max()) if dist.numel() else 0.0,
+                max_latent_abs_diff=float((y - y_cpu).abs().max()))
 
 
 def batch_variants(tiles_dev, n):
@@ -188,15 +211,28 @@ def timed_run(coder, batches, steps, world, dist, cdev):
     cpu0, thr0 = time.process_time(), _throttled()
     t0 = time.perf_counter()
     local_stats, _ = coder.run(seq)
+    t_run = time.perf_counter() - t0
     local_stats = local_stats.to(cdev)
+    g0 = time.perf_counter()
     all_stats = slide.gather_stats(local_stats)  # the one collective of the path (RCCL all_gather)
+    torch.cuda.synchronize()
+    t_gather = time.perf_counter() - g0
     fence()
     dt = time.perf_counter() - t0
     thr1 = _throttled()
     HOST_USE.update(cpus_busy=(time.process_time() - cpu0) / dt,
                     cgroup_throttled_periods=None if thr0 is None else thr1[0] - thr0[0],
-                    cgroup_throttled_ms=None if thr0 is None else (thr1[1] - thr0[1]) / 1e3)
+                    cgroup_throttled_ms=None if thr0 is None else (thr1[1] - thr0[1]) / 1e3,
+                    all_gather_ms=1e3 * t_gather)
     if world > 1:
+        # every rank's own clock, host use and collective time, so that a scaling curve explains itself
+        mine = torch.tensor([dt, t_run, t_gather, HOST_USE['cpus_busy'], HOST_USE['cgroup_throttled_ms'] or 0.0,
+                             float(len(os.sched_getaffinity(0)))], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        HOST_USE['per_rank'] = [dict(rank=r, seconds=float(v[0]), run_seconds=float(v[1]), all_gather_ms=1e3 * float(v[2]),
+                                     cpus_busy=float(v[3]), cgroup_throttled_ms=float(v[4]), cpus_allowed=int(v[5]))
+                                for r, v in enumerate(every)]
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -379,7 +415,7 @@ def main():
                                             for k in ('host_encode', 'host_decode')}
         line['cpu_baseline'] = None
         if world == 1 and not args.no_cpu_baseline:
-            report, per_tile, cpu_payloads, cpu_recs = cpu_baseline(state, cfg, list(tiles_host[:16]))
+            report, per_tile, cpu_payloads, cpu_recs, cpu_latents = cpu_baseline(state, cfg, list(tiles_host[:16]))
             line['cpu_baseline'] = report
             # the GPU path on exactly the tiles the oracle coded (BASELINE's "PSNR/bpp parity" at full tile size)
             n = len(per_tile)
@@ -396,10 +432,28 @@ def main():
                 'psnr_gpu': psnr(float(stats[:, 1].sum()) / n), 'psnr_cpu': psnr(sum(p[1] for p in per_tile) / n),
                 'bitstreams_identical': int(sum(a == b for a, b in zip(payloads, cpu_payloads))),
                 'max_abs_delta': int(diff.max()), 'pixels_differing_frac': float((diff > 0).mean()),
-                'note': 'max_abs_delta in uint8 levels between the GPU and the CPU reconstruction of the same tiles; a '
-                        'bitstream differs where a latent sits within float noise of a rounding boundary',
+                'note': 'symbols_flipped: symbols of the GPU latents that differ from those of the CPU oracle\'s own '
+                        'latents (the integer step is bit-exact given identical latents); max_boundary_distance: how far '
+                        'the two latents of a flipped symbol sit from the rounding boundary between them, at most; '
+                        'max_abs_delta in uint8 levels between the two reconstructions (where a flipped symbol lands)',
             }
+            ref32 = make_coder(cae, slide, state, 'fp32' if f16 else 'f16x3')
+            for name, cd in ((args.precision, coder), ('fp32' if f16 else 'f16x3', ref32)):
+                line['parity_vs_cpu'][name] = flip_report(cd.enc, cd.eb, tiles_dev[:n].contiguous(), cpu_latents)
+            del ref32
         if world == 1 and not args.no_sub_runs:
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import dropin_bench
+            d = dropin_bench.measure(coder.codec, tiles_host, (1, 8, 16), budget_s=1.5)
+            coder.codec.close()
+            line['dropin'] = {
+                'pattern': 'T threads x codec.encode(chunk) / codec.decode(buf), one 1024x1024x3 chunk per call, one shared '
+                           'codec; host arrays in and out (PCIe inside the number)',
+                'encode_tiles_per_s': d['encode'], 'decode_tiles_per_s': d['decode'],
+                'pipelined_round_trip_tiles_per_s': total_tiles / dt,
+                'cpus_busy': d['cpus_busy'], 'mean_gpu_batch': d.get('mean_batch'), 'ms_per_call': d.get('ms_per_call'),
+                'payloads_identical_to_encode_batch': d['identical'],
+            }
             other = 'fp32' if f16 else 'f16x3'
             del coder
             torch.cuda.empty_cache()

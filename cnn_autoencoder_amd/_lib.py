@@ -96,6 +96,14 @@ SYMBOLS = {
     'cae_rans_encode_batch': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),
     'cae_rans_encode_packed': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),
     'cae_rans_decode_batch': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int]),
+    'cae_door_create': (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    'cae_door_destroy': (None, [c_void_p]),
+    'cae_door_encode': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p),
+                                ctypes.POINTER(c_size_t)]),
+    'cae_door_decode_shape': (c_int, [c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                      ctypes.POINTER(c_int)]),
+    'cae_door_decode': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
+    'cae_door_stats': (c_int, [c_void_p, c_void_p, c_int, c_int]),
 }
 
 CAE_ANALYSIS, CAE_SYNTHESIS = 0, 1

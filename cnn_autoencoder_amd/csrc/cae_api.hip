@@ -282,6 +282,17 @@ int Model::ensure_ws(int which, size_t bytes) {
     return CAE_OK;
 }
 
+int Model::order_stream(void *stream) {
+    if (last_stream_set && last_stream != stream) {
+        if (!order_event) HIP_TRY(hipEventCreateWithFlags((hipEvent_t *)&order_event, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord((hipEvent_t)order_event, (hipStream_t)last_stream));
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)order_event, 0));
+    }
+    last_stream = stream;
+    last_stream_set = true;
+    return CAE_OK;
+}
+
 int Model::ensure_device() {
     if (!zero) {
         HIP_TRY(hipMalloc((void **)&zero, 1024));  // zero page: out-of-range halo source, null medians (192 floats)
@@ -329,6 +340,7 @@ static void free_stages(Layer &l) {
 }
 
 Model::~Model() {
+    if (order_event) (void)hipEventDestroy((hipEvent_t)order_event);
     for (auto *tr : {&enc, &dec})
         for (auto &l : *tr) {
             if (l.wp) (void)hipFree(l.wp);
@@ -759,7 +771,7 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(m->mu);
     int rc;
-    if ((rc = m->ensure_device())) return rc;
+    if ((rc = m->ensure_device()) || (rc = m->order_stream(stream))) return rc;
     const bool f16 = m->f16_usable();
     const bool first_fused = f16 ? m->enc[0].wp_edge16 != nullptr : m->enc[0].wp_edge != nullptr;
     int64_t ticket = 0;
@@ -931,7 +943,7 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(m->mu);
     int rc;
-    if ((rc = m->ensure_device())) return rc;
+    if ((rc = m->ensure_device()) || (rc = m->order_stream(stream))) return rc;
     const bool f16 = m->f16_usable();
     int64_t ticket = 0;
     g_last_ticket = 0;
@@ -1112,7 +1124,7 @@ int cae_gdn_forward(cae_model_t *mm, int track, int index, const float *x, int n
     if (!l.set || !l.gdn) return fail(CAE_ERR_ARG, "layer has no GDN");
     const int planes = l.ct * 4;
     int rc;
-    if ((rc = m->ensure_device())) return rc;
+    if ((rc = m->ensure_device()) || (rc = m->order_stream(stream))) return rc;
     if ((rc = m->ensure_ws(0, (size_t)n * planes * h * w * 32))) return rc;
     const size_t tot = (size_t)n * planes * h * w;
     hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, x, (float *)m->ws[0], n, l.cout, h * w,

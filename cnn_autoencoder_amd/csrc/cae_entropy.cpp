@@ -156,8 +156,10 @@ static int count_steps(const EntropyTables &T, const int32_t *symbols, int hw, s
 }
 
 // symbols[k]: (channels, hw) int32 in (c, y, x) raster order
+// `headroom`: bytes left free in front of every returned stream (the codec's 16-byte chunk header)
 template <int NS>
-int encode_streams(const EntropyTables &T, const int32_t *const *symbols, int hw, uint8_t **out, size_t *out_len) {
+int encode_streams(const EntropyTables &T, const int32_t *const *symbols, int hw, uint8_t **out, size_t *out_len,
+                   size_t headroom = 0) {
     uint32_t *buf[NS] = {};
     size_t cap[NS];
     BackWriter w[NS];
@@ -230,13 +232,13 @@ int encode_streams(const EntropyTables &T, const int32_t *const *symbols, int hw
         w[k].put((uint32_t)(x[k] >> 32));
         w[k].put((uint32_t)x[k]);
         const size_t nbytes = (size_t)((buf[k] + cap[k]) - w[k].ptr) * sizeof(uint32_t);
-        uint8_t *res = (uint8_t *)malloc(nbytes ? nbytes : 1);
+        uint8_t *res = (uint8_t *)malloc(headroom + nbytes ? headroom + nbytes : 1);
         if (!res) {
-            rc = fail(CAE_ERR_NOMEM, "out of memory (%zu bytes)", nbytes);
+            rc = fail(CAE_ERR_NOMEM, "out of memory (%zu bytes)", headroom + nbytes);
         } else {
-            memcpy(res, w[k].ptr, nbytes);
+            memcpy(res + headroom, w[k].ptr, nbytes);
             out[k] = res;
-            out_len[k] = nbytes;
+            out_len[k] = headroom + nbytes;
         }
         free(buf[k]);
     }
@@ -404,6 +406,31 @@ int parallel_streams(int n, int threads, F f) {
 }
 
 }  // namespace
+
+// one / two streams coded by the calling thread (the codec front door: cae_door.hip)
+int rans_encode_chunk(const EntropyTables &T, const int32_t *symbols, int hw, size_t headroom, uint8_t **out,
+                      size_t *out_len) {
+    const int32_t *sy[1] = {symbols};
+    return encode_streams<1>(T, sy, hw, out, out_len, headroom);
+}
+
+int rans_encode_chunk_pair(const EntropyTables &T, const int32_t *const *symbols, int hw, size_t headroom, uint8_t **out,
+                           size_t *out_len) {
+    return encode_streams<2>(T, symbols, hw, out, out_len, headroom);
+}
+
+int rans_decode_chunk(const EntropyTables &T, const uint8_t *buf, size_t len, int hw, int32_t *symbols) {
+    const uint8_t *b[1] = {buf};
+    const size_t l[1] = {len};
+    int32_t *sy[1] = {symbols};
+    return decode_streams<1>(T, b, l, hw, sy);
+}
+
+int rans_decode_chunk_pair(const EntropyTables &T, const uint8_t *const *bufs, const size_t *lens, int hw,
+                           int32_t *const *symbols) {
+    return decode_streams<2>(T, bufs, lens, hw, symbols);
+}
+
 }  // namespace cae
 
 using namespace cae;

@@ -62,6 +62,15 @@ struct EntropyTables {
     void build_tables();
 };
 
+// single chunks coded by the calling thread (cae_entropy.cpp); `headroom` bytes stay free in front of the stream
+int rans_encode_chunk(const EntropyTables &T, const int32_t *symbols, int hw, size_t headroom, uint8_t **out,
+                      size_t *out_len);
+int rans_encode_chunk_pair(const EntropyTables &T, const int32_t *const *symbols, int hw, size_t headroom, uint8_t **out,
+                           size_t *out_len);
+int rans_decode_chunk(const EntropyTables &T, const uint8_t *buf, size_t len, int hw, int32_t *symbols);
+int rans_decode_chunk_pair(const EntropyTables &T, const uint8_t *const *bufs, const size_t *lens, int hw,
+                           int32_t *const *symbols);
+
 struct Model {
     int c_org = 0, c_net = 0, c_bn = 0, L = 0, ks = 3;
     std::vector<Layer> enc, dec;
@@ -96,6 +105,12 @@ struct Model {
     bool f16_usable() const;
     int ensure_ws(int which, size_t bytes);
     int ensure_device();
+    // The workspaces are used in CALL order whatever stream a call names: a call on another stream than the one before
+    // waits (on the device) for that one's work (order_stream, under `mu`).
+    void *last_stream = nullptr;
+    bool last_stream_set = false;
+    void *order_event = nullptr;
+    int order_stream(void *stream);
     ~Model();
 };
 

@@ -330,6 +330,42 @@ int cae_rans_encode_packed(cae_model_t *m, const int32_t *symbols_host, int n_st
 int cae_rans_decode_batch(cae_model_t *m, const uint8_t *const *bufs, const size_t *lens, int n_streams,
                           int hw, int32_t *symbols_host, int threads);
 
+/* ---- codec front door -------------------------------------------------------------------
+ * The reference's numcodecs plugin contract as C entry points: ConvolutionalAutoencoder.encode
+ * (_autoencoders.py:539-555: (h,w,c) uint8 chunk -> '>QQ' header + rANS payload) and .decode (:557-584: chunk bytes ->
+ * (H,W,c) uint8 tile), one chunk per call, called CONCURRENTLY from dask's thread pool on one shared codec
+ * (compress.py:121-128, decompress.py:51-58).  Both calls block and are thread-safe without any caller-side lock.  The
+ * range coder of a chunk runs in the calling thread; the GPU parts of the calls that are waiting at the same time are
+ * launched as ONE batch (chunks of equal shape, at most max_batch) as soon as one of `inflight` device-side slots is
+ * free -- no timer: a lone caller is served at once.  Results do not depend on the grouping.
+ *
+ * analysis / synthesis: the two track handles of the codec (cae_model_set_layer ... and cae_model_set_entropy done on
+ * BOTH: the encode side codes with the analysis handle's tables, the decode side with the synthesis handle's); the
+ * door does not own them, they must outlive it and must not be re-configured while calls are in flight.  The handles
+ * stay usable through the other entry points on any stream (calls on a handle are ordered on the device in call
+ * order).  max_batch <= 0: 32; inflight <= 0: 3.  HIP device = the calling thread's current device.
+ * cae_door_destroy serves the queued calls first; no call may be running or started once it has been entered. */
+typedef struct cae_door cae_door_t;
+int cae_door_create(cae_model_t *analysis, cae_model_t *synthesis, int max_batch, int inflight, cae_door_t **out);
+void cae_door_destroy(cae_door_t *door);
+/* Codec.encode: tile_host (h,w,c) uint8 C-contiguous (any host memory).  *out: library-allocated chunk (cae_free) =
+ * 16-byte big-endian (h,w) header + rANS payload, *out_len its length. */
+int cae_door_encode(cae_door_t *door, const uint8_t *tile_host, int h, int w, int c, uint8_t **out, size_t *out_len);
+/* Shape of the tile a chunk decodes to: H = (h >> L) << L as the reference derives the latent size (floor, :565). */
+int cae_door_decode_shape(cae_door_t *door, const uint8_t *chunk_host, size_t len, int *h, int *w, int *c);
+/* Codec.decode: chunk bytes -> out_host (H,W,c) uint8 (capacity in bytes >= H*W*c). */
+int cae_door_decode(cae_door_t *door, const uint8_t *chunk_host, size_t len, uint8_t *out_host, size_t out_capacity);
+/* Counters since creation / the last reset: batches launched, chunks served, batches repeated on the fp32 kernels,
+ * then seconds summed over the calls: caller staging (copy into pinned memory / range decode), caller waiting, caller
+ * coding (range encode / copy out), and the waiting time split into queue, launch, device, pull (DMA to the host) and
+ * wake-up. */
+enum cae_door_stat {
+    CAE_DOOR_STAT_BATCHES = 0, CAE_DOOR_STAT_CHUNKS, CAE_DOOR_STAT_FP32_REPEATS, CAE_DOOR_STAT_T_STAGE,
+    CAE_DOOR_STAT_T_WAIT, CAE_DOOR_STAT_T_CODE, CAE_DOOR_STAT_T_QUEUE, CAE_DOOR_STAT_T_LAUNCH, CAE_DOOR_STAT_T_DEVICE,
+    CAE_DOOR_STAT_T_PULL, CAE_DOOR_STAT_T_WAKE, CAE_DOOR_STATS
+};
+int cae_door_stats(cae_door_t *door, double *stats /* n */, int n, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,101 +2,31 @@
 codec (dask's threaded scheduler, ``src/compress.py:121-128``; bodies ``_autoencoders.py:539-584``).  The front door
 coalesces the GPU part of concurrent calls; results must not depend on how calls were grouped."""
 import struct
-import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import pytest
 
 
-# ---- host logic (no GPU): grouping, limits, error routing of the dispatcher ----------------------------------------
-class _FakeDoor:
-    """FrontDoor with the two GPU steps replaced: `_launch` records the batch, `_complete` answers (batch size, index).
-    (The service loops pin the door's device first: the tests below stub torch.cuda.set_device.)"""
-
-    def __new__(cls, max_batch=4, inflight=1, gate=None, fail_key=None):
-        from cnn_autoencoder_amd import frontdoor as fd
-
-        class Door(fd.FrontDoor):
-            def __init__(self):  # no codec, no device
-                import queue
-                self.max_batch, self.inflight = max_batch, inflight
-                self.dev = None
-                self._q, self._cq = queue.Queue(), queue.Queue()
-                self._slots = threading.local()
-                self._sem = threading.Semaphore(inflight)
-                self._started = self._closed = False
-                self._start_mu = threading.Lock()
-                self.batches = self.chunks = 0
-                self._timers = []
-                self.seen = []
-
-            def _launch(self, batch):
-                if gate is not None:
-                    gate.wait()
-                self.seen.append([r.key for r in batch])
-                if fail_key is not None and batch[0].key[1] == fail_key:
-                    raise ValueError('bad batch')
-                return (batch,)
-
-            def _complete(self, batch):
-                for i, r in enumerate(batch):
-                    r.result = (len(batch), i)
-                    r.batch = None
-                    r.done.set()
-
-        return Door()
-
-
-def test_dispatcher_groups_by_key_and_respects_max_batch(monkeypatch):
-    import torch
-    from cnn_autoencoder_amd import frontdoor as fd
-    monkeypatch.setattr(torch.cuda, 'set_device', lambda d: None)
-    gate = threading.Event()
-    door = _FakeDoor(max_batch=4, inflight=1, gate=gate)
-    # 6 requests of shape A, 3 of shape B queued while the dispatcher is held at its first launch
-    with ThreadPoolExecutor(12) as pool:
-        first = pool.submit(door._submit, fd._ENCODE, ('A',), {})
-        while not door._started or door._q.qsize() > 0:  # the dispatcher took the first request and waits at the gate
-            threading.Event().wait(0.01)
-        futs = []
-        for key in ['A'] * 6 + ['B'] * 3:
-            futs.append(pool.submit(door._submit, fd._ENCODE, (key,), {}))
-            while door._q.qsize() < len(futs):
-                threading.Event().wait(0.005)
-        gate.set()
-        res = [f.result(timeout=20) for f in [first] + futs]
-    door.close()
-    sizes = [len(b) for b in door.seen]
-    assert sizes == [1, 4, 2, 3], sizes  # first alone; A's split at max_batch; B's never mixed with A's
-    assert all(len({k for k in b}) == 1 for b in door.seen)
-    assert sorted(r.result[1] for r in res[1:5]) == [0, 1, 2, 3]
-
-
-def test_dispatcher_routes_errors_to_the_callers_of_that_batch_only(monkeypatch):
-    import torch
-    from cnn_autoencoder_amd import frontdoor as fd
-    monkeypatch.setattr(torch.cuda, 'set_device', lambda d: None)
-    door = _FakeDoor(max_batch=8, inflight=2, fail_key='bad')
-    with ThreadPoolExecutor(8) as pool:
-        good = [pool.submit(door._submit, fd._ENCODE, ('ok',), {}) for _ in range(5)]
-        bad = [pool.submit(door._submit, fd._DECODE, ('bad',), {}) for _ in range(2)]
-        assert all(f.result(timeout=20).result is not None for f in good)
-        for f in bad:
-            with pytest.raises(ValueError, match='bad batch'):
-                f.result(timeout=20)
-        # the door keeps serving after a failed batch
-        assert pool.submit(door._submit, fd._ENCODE, ('ok',), {}).result(timeout=20).result is not None
-    door.close()
-    with pytest.raises(RuntimeError):
-        door._closed = True
-        door._started = False
-        door._ensure_started()
+# ---- host side (no GPU): the C ABI of the door is exported and refuses what it must ------------------------------------
+def test_door_symbols_and_argument_checks(built_lib):
+    import ctypes
+    from cnn_autoencoder_amd import _lib
+    L = _lib.lib()
+    for name in ('cae_door_create', 'cae_door_destroy', 'cae_door_encode', 'cae_door_decode_shape', 'cae_door_decode',
+                 'cae_door_stats'):
+        assert hasattr(L, name)
+    door = ctypes.c_void_p()
+    assert L.cae_door_create(None, None, 0, 0, ctypes.byref(door)) == -1  # CAE_ERR_ARG, no device touched
+    assert b'NULL' in L.cae_last_error()
+    assert L.cae_door_encode(None, None, 4, 4, 3, None, None) == -1
+    assert L.cae_door_decode(None, None, 0, None, 0) == -1
+    L.cae_door_destroy(None)  # a no-op
 
 
 # ---- on the GPU --------------------------------------------------------------------------------------------------
 @pytest.fixture(scope='module')
-def cae():
+def cae(built_lib):
     import torch
     if not torch.cuda.is_available():
         pytest.skip('needs a HIP device')
@@ -123,8 +53,9 @@ def test_sixteen_threads_match_the_batched_side_door(cae):
     order = np.random.default_rng(0).permutation(len(tiles))
     got = _run_threads(16, lambda i: (i, codec.encode(tiles[i])), order)
     door = codec._front_door()
-    assert door is not None and door.chunks == len(tiles)
-    assert door.batches < len(tiles), 'no call was ever coalesced'
+    st = door.stats()
+    assert door is not None and st['chunks'] == len(tiles)
+    assert st['batches'] < len(tiles), 'no call was ever coalesced'
     for i, buf in got:
         assert buf == ref[i], f'tile {i}: payload differs from encode_batch'
     rec_ref = list(codec.decode_batch(ref[:len(a)])) + list(codec.decode_batch(ref[len(a):]))
@@ -141,6 +72,34 @@ def test_sixteen_threads_match_the_batched_side_door(cae):
     mixed = _run_threads(16, lambda i: codec.encode(tiles[i]) if i % 3 else codec.decode(ref[i]), order)
     for i, r in zip(order, mixed):
         assert (r == ref[i]) if i % 3 else np.array_equal(r, rec_ref[i])
+    codec.close()
+
+
+@pytest.mark.gpu
+def test_batch_limit_and_shapes_are_never_mixed(cae):
+    """max_batch = 3, one in-flight slot: every batch holds at most 3 chunks of ONE shape; 40 calls from 12 threads."""
+    from cnn_autoencoder_amd import synth
+    from cnn_autoencoder_amd.frontdoor import FrontDoor
+    state = synth.synthetic_state(dict(synth.CANONICAL, channels_net=32, channels_bn=48, compression_level=3), seed=6)
+    codec = cae.ConvolutionalAutoencoder(checkpoint=state)
+    a, b = synth.uniform_tiles(24, 64), synth.uniform_tiles(16, 40, 72)
+    ref = codec.encode_batch(a) + codec.encode_batch(b)
+    tiles = list(a) + list(b)
+    door = FrontDoor(codec, max_batch=3, inflight=1)
+    order = np.random.default_rng(1).permutation(len(tiles))
+    got = _run_threads(12, lambda i: (i, door.encode(tiles[i])), order)
+    assert all(buf == ref[i] for i, buf in got)
+    st = door.stats()
+    assert st['chunks'] == 40 and st['batches'] >= 14  # ceil(24/3) + ceil(16/3)
+    rec = _run_threads(12, lambda i: (i, door.decode(ref[i])), order)
+    want = list(codec.decode_batch(ref[:24])) + list(codec.decode_batch(ref[24:]))
+    assert all(np.array_equal(r, want[i]) for i, r in rec)
+    # buffer-protocol inputs (zarr hands over whatever the store returned) and a header-only chunk
+    assert np.array_equal(door.decode(bytearray(ref[0])), want[0])
+    assert np.array_equal(door.decode(memoryview(ref[30])), want[30])
+    with pytest.raises(Exception):
+        door.decode(ref[0][:12])
+    door.close()
     codec.close()
 
 
@@ -200,10 +159,11 @@ def test_range_guard_repeat_through_the_door(cae):
     tiles = np.random.default_rng(5).integers(200, 256, (6, 64, 96, 3), dtype=np.uint8)
     ref = codec.encode_batch(tiles)
     enc = codec._model['encoder'].module
-    before = enc.fp32_fallbacks
     got = _run_threads(6, codec.encode, list(tiles))
     assert got == ref
+    st = codec._front_door().stats()
     if enc.precision_code() == 1:
-        assert enc.fp32_fallbacks > before, 'the stress weights did not trip the guard'
-    assert torch.cuda.is_available()
+        assert st['fp32_repeats'] >= 1, 'the stress weights did not trip the guard'
+    rec = _run_threads(6, codec.decode, ref)
+    assert all(np.array_equal(r, w) for r, w in zip(rec, codec.decode_batch(ref)))
     codec.close()

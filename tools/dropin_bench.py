@@ -37,17 +37,19 @@ def measure(codec, tiles: np.ndarray, thread_counts: Sequence[int] = (1, 8, 16),
         for name, fn, data in (('encode', codec.encode, items), ('decode', codec.decode, ref)):
             dt1, _, _ = _drive(fn, data, T, 1)  # also the warm-up of this thread count
             repeat = int(max(1, min(64, budget_s / max(dt1, 1e-3))))
-            b0, c0 = (door.batches, door.chunks) if door is not None else (0, 0)
             if door is not None:
-                door.timers(reset=True)
+                door.stats(reset=True)
             dt, cpu, res = _drive(fn, data, T, repeat)
             out[name][str(T)] = repeat * len(data) / dt
             out['cpus_busy'][f'{name}{T}'] = cpu / dt
             if door is not None:
-                out.setdefault('mean_batch', {})[f'{name}{T}'] = (door.chunks - c0) / max(1, door.batches - b0)
-                # ms per chunk (callers' stages: averaged per call; service threads: per chunk served)
-                out.setdefault('ms_per_chunk', {})[f'{name}{T}'] = {
-                    k: round(1e3 * v / (repeat * len(data)), 4) for k, v in sorted(door.timers().items())}
+                st = door.stats()
+                out.setdefault('mean_batch', {})[f'{name}{T}'] = st['chunks'] / max(1.0, st['batches'])
+                # a call's milliseconds inside the library, averaged over the calls: staging (copy into pinned memory /
+                # range decode), waiting (split: queue, launch, device, pull, wake-up), coding (range encode / copy out)
+                out.setdefault('ms_per_call', {})[f'{name}{T}'] = {
+                    k: round(1e3 * v / max(1.0, st['chunks']), 4) for k, v in st.items()
+                    if k not in ('batches', 'chunks', 'fp32_repeats')}
                 out.setdefault('wall_ms_per_chunk', {})[f'{name}{T}'] = round(1e3 * dt / (repeat * len(data)), 4)
             same = (res == ref) if name == 'encode' else all(np.array_equal(a, b) for a, b in zip(res, rec_ref))
             out['identical'] = bool(out['identical'] and same)
