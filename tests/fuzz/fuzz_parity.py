@@ -5,6 +5,9 @@ usage: fuzz_parity.py [n_cases] [seed] [first_case]   -> prints failures, exits 
 (first_case > 0: the earlier cases only advance the generator; every case is then announced before it touches the GPU, so a
 faulting one can be named from the log)"""
 import os, sys, time
+# every over-read becomes a deterministic fault instead of a silent read of allocator slack (set before HIP starts;
+# HSA_DISABLE_FRAGMENT_ALLOCATOR=0 in the environment keeps the default allocator)
+os.environ.setdefault('HSA_DISABLE_FRAGMENT_ALLOCATOR', '1')
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -14,8 +17,11 @@ from cnn_autoencoder_amd import synth
 from test_host import cpu_track
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
 first_case = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+print(f'fuzz_parity: seed {seed}, {n_cases} cases from case {first_case}, HSA_DISABLE_FRAGMENT_ALLOCATOR='
+      f'{os.environ["HSA_DISABLE_FRAGMENT_ALLOCATOR"]} (tools/replay_fuzz.py lists a sweep\'s cases on the host)', flush=True)
 fails = skipped = 0
 t_start = time.time()
 for case in range(n_cases):

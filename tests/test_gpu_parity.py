@@ -311,6 +311,47 @@ def test_full_size_properties(cae):
                                rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('kind', ['histo', 'uniform'])
+def test_full_size_tile_against_the_oracle(cae, kind, precision):
+    """BASELINE's tile size (canonical 128/192/L4 model, one 1024x1024x3 tile of each synthetic kind), both arithmetic
+    paths, against the CPU oracle: latents within 1e-4, payload == the oracle's C coder on the GPU's latents, decode
+    of those bytes within 1 LSB of the oracle's decode, and the float -> integer cliff COUNTED: symbols of the GPU
+    latents vs symbols of the oracle's own latents (786 432 per tile; a flip needs both latents within float noise of
+    the rounding boundary)."""
+    from oracle import c_oracle as C
+    from oracle import cae_oracle as O
+    from cnn_autoencoder_amd import synth
+    state = synth.synthetic_state(synth.CANONICAL, seed=0)
+    codec = cae.ConvolutionalAutoencoder(checkpoint=state)
+    enc = codec._model['encoder'].module
+    assert enc.precision_code() == (1 if precision == 'f16x3' else 0)
+    tile = synth.histo_tile(1024, 3) if kind == 'histo' else synth.uniform_tiles(1, 1024)[0]
+    o = O.EntropyBottleneckOracle(192)
+    o.load(state['fact_ent'])
+    o.update()
+    y_ref, _ = O.analysis_forward(O.tile_to_input(tile), oracle_layers(state, 'encoder'))
+    y_gpu = enc.forward_u8(torch.from_numpy(tile)[None].cuda()).cpu()
+    np.testing.assert_allclose(y_gpu.numpy(), y_ref.numpy(), rtol=RTOL, atol=ATOL)
+    buf = codec.encode(tile)
+    assert struct.unpack('>QQ', buf[:16]) == (1024, 1024)
+    assert buf[16:] == o.compress(y_gpu, C.rans_encode_with_indexes)[0]
+    s_gpu, s_ref = o.symbols(y_gpu), o.symbols(y_ref)
+    assert s_gpu.numel() == 786432
+    flips = s_gpu != s_ref
+    n_flips = int(flips.sum())
+    assert n_flips <= 16, f'{n_flips} of 786432 symbols differ from the oracle latents\' symbols'
+    if n_flips:
+        med = o.medians().reshape(1, -1, 1, 1)
+        bound = torch.minimum(s_gpu, s_ref).float() + 0.5
+        dist = torch.maximum((y_gpu - med - bound).abs(), (y_ref - med - bound).abs())[flips]
+        assert int((s_gpu - s_ref).abs().max()) == 1 and float(dist.max()) < 2e-5, float(dist.max())
+    rec = codec.decode(buf)
+    ref_rec = O.codec_decode(buf, oracle_layers(state, 'decoder'), o, C.rans_decode_with_indexes)
+    diff = np.abs(rec.astype(int) - ref_rec.astype(int))
+    assert rec.shape == (1024, 1024, 3) and diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    codec.close()
+
+
 @pytest.mark.parametrize('ks,shape', [(3, (3, 1000, 1016)), (5, (2, 520, 488)), (3, (1, 2048, 1040))])
 def test_arithmetic_paths_agree_on_large_ragged_tiles(cae, ks, shape):
     """Sizes the CPU oracle cannot reach in seconds: the exact-fp32 kernels and the f16x3 kernels (different tiling,
