@@ -27,6 +27,8 @@ Objects in the line besides the driver's contract:
   cpu_baseline  the CPU oracle (torch-CPU conv + restated GDN + C rANS) on a bounded sample of the
                 same tiles on this host's cores -- a reported baseline, not the target
   parity_vs_cpu the GPU path against that oracle on the very same tiles: bpp, PSNR, bitstreams, pixels
+  train         (N=1) BASELINE config 5: train.train_step on 256x256 patches, batch 16 and 128, against the mixed
+                bf16-conv / fp32-GDN roofline
   dropin        (N=1) the reference's OWN call pattern: 1 / 8 / 16 Python threads calling codec.encode(chunk) /
                 codec.decode(buf) one 1024^2 chunk at a time on one shared codec (dask's threaded scheduler,
                 compress.py:121-128), host memory in, host memory out: tiles/s of each direction, next to the
@@ -282,6 +284,50 @@ def sub_run(cae, slide, cfg, state, precision, H, tiles_dev, steps, warmup, dist
                 fp32_fallbacks=fallbacks)
 
 
+def train_flops(cfg, patch):
+    """Algorithmic FLOP of one training sample (config 5, train_cae_ms.py:209-230), split by the arithmetic it runs in:
+    convolutions (bf16 MFMA): forward + weight gradient of every layer + data gradient of every layer but the first
+    analysis layer (the image needs no gradient); GDN / IGDN contractions (fp32 MFMA): forward + the two backward
+    contractions (Gamma^T g_n and g_Gamma = g_n (x) z^2; recomputing the norm in the backward is an implementation
+    choice and is NOT counted)."""
+    plain = dict(cfg, act_layer_type=None)
+    enc_c, dec_c = layer_flops(plain, patch, patch)
+    enc_a, dec_a = layer_flops(cfg, patch, patch)
+    conv = 3.0 * (sum(enc_c) + sum(dec_c)) - enc_c[0]
+    gdn = 3.0 * ((sum(enc_a) - sum(enc_c)) + (sum(dec_a) - sum(dec_c)))
+    return conv, gdn
+
+
+def train_run(cae, cfg, state, batch, patch, steps, warmup):
+    """`steps` iterations of train.train_step (forward_func -> GeneralLoss -> backward -> clip -> per-module Adam) on one
+    synthetic batch resident in HBM.  -> report with the fraction of the MIXED roofline: bf16 convolution FLOP / the dense
+    bf16 MFMA peak + fp32 GDN FLOP / the fp32 MFMA peak, over the measured step time."""
+    from cnn_autoencoder_amd import criteria, train
+    model = cae.autoencoder_from_state_dict(state, train=True)
+    opts = train.setup_optim(model)
+    criterion = criteria.GeneralLoss(distortion_lambda=0.01)
+    x = torch.rand(batch, cfg['channels_org'], patch, patch, device='cuda', generator=torch.Generator('cuda').manual_seed(1))
+    for _ in range(warmup):
+        train.train_step(x, model, criterion, opts)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        ld = train.train_step(x, model, criterion, opts)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    conv, gdn = train_flops(cfg, patch)
+    ideal = batch * (conv / (F16_MFMA_PEAK_TFLOPS * 1e12) + gdn / (FP32_MFMA_PEAK_TFLOPS * 1e12))
+    del model, opts
+    torch.cuda.empty_cache()
+    return dict(batch=batch, patch=patch, steps=steps, ms_per_step=1e3 * dt, samples_per_s=batch / dt,
+                device_ms_per_step=e0.elapsed_time(e1) / steps,
+                conv_gflop_per_step=batch * conv / 1e9, gdn_gflop_per_step=batch * gdn / 1e9,
+                mixed_roofline_ms=1e3 * ideal, frac=ideal / dt, loss=float(ld['loss']))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -461,6 +507,16 @@ def main():
             t256 = torch.from_numpy(synth.histo_tiles(64, 256, first_index=10_000)).to(dev)
             t256 = torch.cat(batch_variants(t256, 8))  # 512 tiles per step
             line['tile256'] = sub_run(cae, slide, cfg, state, args.precision, 256, t256, 16, 2, dist)
+            del t256
+            torch.cuda.empty_cache()
+            # BASELINE config 5 (train_cae_ms.py rate-distortion loop): canonical model, 256x256 patches
+            line['train'] = {
+                'dtype': 'bf16 convolutions (fp32 accumulate), fp32 GDN / IGDN (v_mfma_f32_32x32x2_f32), fp32 optimiser',
+                'roofline': 'mixed: conv FLOP / 2500 TFLOP/s (dense bf16 MFMA) + GDN FLOP / 157.3 TFLOP/s (fp32 MFMA); '
+                            'frac = that time / measured step time',
+                'batch16': train_run(cae, cfg, state, 16, 256, 20, 3),
+                'batch128': train_run(cae, cfg, state, 128, 256, 8, 2),
+            }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -81,6 +81,10 @@ SYMBOLS = {
     'cae_t_gdn_forward': (c_int, [c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'cae_t_gdn_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cae_t_gdn_saved_elems': (c_size_t, [ctypes.c_long, c_int]),
+    'cae_t_gdn_forward_save': (c_int, [c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'cae_t_gdn_backward_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     'cae_t_fold_to_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_t_colsum': (c_int, [c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p]),
     'cae_t_density_params': (c_int, [c_int, c_int]),

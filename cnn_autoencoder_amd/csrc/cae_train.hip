@@ -3,6 +3,7 @@
 #include "cae_internal.hpp"
 #include "cae_launch.hpp"
 #include "cae_train_kernels.hpp"
+#include "cae_train_gdn.hpp"
 
 #include <algorithm>
 
@@ -212,6 +213,39 @@ int launch_gdn_b_t(const float *gn, const float *z, long pixels, float *gg, floa
     return CAE_OK;
 }
 
+template <int CT>
+int launch_gdn_fused_t(const GdnFusedArgs &a, bool backward, hipStream_t st) {
+    constexpr int C = CT * 32;
+    constexpr int LDS_F = C * (C + 4) * 4 + 2 * 64 * C * 4 + 64 * (C * 2 + 16);
+    constexpr int LDS_B = C * (C + 4) * 4 + 4 * 32 * C * 4 + 32 * (C * 2 + 16);
+    auto kf = gdn_fwd_fused_kernel<CT>;
+    auto kb = gdn_bwd_fused_kernel<CT>;
+    static bool done = false;
+    if (!done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F));
+        HIP_TRY(hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+        done = true;
+    }
+    const long tiles = (a.pixels + (backward ? 31 : 63)) / (backward ? 32 : 64);
+    const unsigned grid = (unsigned)std::min<long>(tiles, 256);  // persistent: one block per CU walks the tiles
+    if (backward)
+        hipLaunchKernelGGL(kb, dim3(grid), dim3(CT * 64), LDS_B, st, a);
+    else
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(CT * 64), LDS_F, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int launch_gdn_fused(const GdnFusedArgs &a, int cp, bool backward, hipStream_t st) {
+    switch (cp / 32) {
+        case 1: return launch_gdn_fused_t<1>(a, backward, st);
+        case 2: return launch_gdn_fused_t<2>(a, backward, st);
+        case 3: return launch_gdn_fused_t<3>(a, backward, st);
+        case 4: return launch_gdn_fused_t<4>(a, backward, st);
+        default: return fail(CAE_ERR_UNSUPPORTED, "fused GDN kernels are built for at most 128 channels, got %d", cp);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -391,6 +425,51 @@ int cae_t_gdn_backward(const float *z32, const float *gext32, int n, int h, int 
         case 5: return launch_gdn_b_t<5>(gn_ws32, z32, pixels, ggamma, gbeta, st);
         default: return launch_gdn_b_t<6>(gn_ws32, z32, pixels, ggamma, gbeta, st);
     }
+}
+
+size_t cae_t_gdn_saved_elems(long pixels, int cp) {
+    if (pixels < 1 || cp < 32 || cp > 128 || cp % 32) return 0;
+    return (size_t)((pixels + 63) / 64) * 64 * (size_t)cp;
+}
+
+int cae_t_gdn_forward_save(const float *z32, long pixels, int cp, const float *beta, const float *gamma, int inverse,
+                           void *y16, float *f_saved, void *stream) {
+    if (!z32 || !beta || !gamma || !y16 || !f_saved) return fail(CAE_ERR_ARG, "NULL argument");
+    if (pixels < 1 || pixels >= (1l << 31) || cp % 32) return fail(CAE_ERR_ARG, "bad shape");
+    GdnFusedArgs a{};
+    a.z = z32;
+    a.gamma = gamma;
+    a.beta = beta;
+    a.f = f_saved;
+    a.y16 = y16;
+    a.pixels = pixels;
+    a.inverse = inverse;
+    return launch_gdn_fused(a, cp, false, (hipStream_t)stream);
+}
+
+int cae_t_gdn_backward_fused(const float *z32, const float *f_saved, const float *gext32, int n, int h, int w, int pad, int cp,
+                             const float *gamma, int inverse, void *gz16, float *ggamma, float *gbeta, void *stream) {
+    if (!z32 || !f_saved || !gext32 || !gamma || !gz16 || !ggamma || !gbeta) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 1 || w < 1 || pad < 0 || cp % 32) return fail(CAE_ERR_ARG, "bad shape");
+    const long pixels = (long)n * h * w;
+    if (pixels >= (1l << 31)) return fail(CAE_ERR_ARG, "more than 2^31 pixels per call");
+    if (cp > 128) return fail(CAE_ERR_UNSUPPORTED, "fused GDN kernels are built for at most 128 channels, got %d", cp);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(ggamma, 0, (size_t)cp * cp * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(gbeta, 0, (size_t)cp * sizeof(float), st));
+    GdnFusedArgs a{};
+    a.z = z32;
+    a.gamma = gamma;
+    a.f = const_cast<float *>(f_saved);
+    a.gy = FoldSrc{gext32, h, w, pad};
+    a.img_h = h;
+    a.img_w = w;
+    a.gz16 = gz16;
+    a.ggamma = ggamma;
+    a.gbeta = gbeta;
+    a.pixels = pixels;
+    a.inverse = inverse;
+    return launch_gdn_fused(a, cp, true, st);
 }
 
 int cae_t_fold_to_bf16(const float *gext32, int n, int h, int w, int pad, int cp, void *out16, void *stream) {

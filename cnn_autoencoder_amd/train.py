@@ -107,19 +107,40 @@ def _to_nchw(t32: torch.Tensor, c: int) -> torch.Tensor:
     return out
 
 
-def _gdn_forward(z32: torch.Tensor, beta_p: torch.Tensor, gamma_p: torch.Tensor, inverse: bool) -> torch.Tensor:
+def _gdn_fused(cp: int) -> bool:
+    """one-kernel GDN forward (saving the factor f, y = z f) / backward (cae_t_gdn_*_save / _fused: up to 128 channels);
+    CAE_GDN_FUSED=0 keeps the three-kernel backward, which the tests use as the comparison"""
+    return cp <= 128 and os.environ.get('CAE_GDN_FUSED', '1') != '0'
+
+
+def _gdn_forward(z32: torch.Tensor, beta_p: torch.Tensor, gamma_p: torch.Tensor, inverse: bool):
+    """-> (y16, saved factor f | None)"""
     n, h, w, cp = z32.shape
     y16 = torch.empty_like(z32, dtype=torch.bfloat16)
     beta, gamma = beta_p.detach().float().contiguous(), gamma_p.detach().float().contiguous()  # (alive across the call)
+    if _gdn_fused(cp):
+        f = torch.empty(_L().cae_t_gdn_saved_elems(n * h * w, cp), dtype=torch.float32, device=z32.device)
+        _lib.check(_L().cae_t_gdn_forward_save(z32.data_ptr(), n * h * w, cp, beta.data_ptr(), gamma.data_ptr(),
+                                               int(inverse), y16.data_ptr(), f.data_ptr(), _st()))
+        return y16, f
     _lib.check(_L().cae_t_gdn_forward(z32.data_ptr(), n * h * w, cp, beta.data_ptr(), gamma.data_ptr(), int(inverse),
                                       None, y16.data_ptr(), _st()))
-    return y16
+    return y16, None
 
 
-def _gdn_backward(z32, gext32, pad, beta_p, gamma_p, inverse):
+def _gdn_backward(z32, gext32, pad, beta_p, gamma_p, inverse, f=None):
     """-> (gz16, g_beta_p, g_gamma_p)"""
     n, h, w, cp = z32.shape
     dev = z32.device
+    if f is not None:
+        gz16 = torch.empty_like(z32, dtype=torch.bfloat16)
+        gg = torch.empty((cp, cp), dtype=torch.float32, device=dev)
+        gb = torch.empty((cp,), dtype=torch.float32, device=dev)
+        gamma = gamma_p.detach().float().contiguous()
+        _lib.check(_L().cae_t_gdn_backward_fused(z32.data_ptr(), f.data_ptr(), gext32.data_ptr(), n, h, w, pad, cp,
+                                                 gamma.data_ptr(), int(inverse), gz16.data_ptr(), gg.data_ptr(),
+                                                 gb.data_ptr(), _st()))
+        return gz16, gb, gg
     gn = torch.empty_like(z32)
     gzd = torch.empty_like(z32)
     gz16 = torch.empty_like(z32, dtype=torch.bfloat16)
@@ -165,10 +186,14 @@ class AnalysisFn(torch.autograd.Function):
             z16 = None if need32 else torch.empty((n, oh, ow, s.cout_p), dtype=torch.bfloat16, device=x.device)
             _lib.check(L.cae_t_conv_forward(a16.data_ptr(), n, h, w, s.cin_p, wp.data_ptr(), s.ks, _ptr(z32), _ptr(z16),
                                             s.cout_p, _ptr(bias_p), _st()))
-            saved.append((a16, z32 if s.has_gdn else None))
+            f_saved = None
+            a16_in = a16
+            if s.has_gdn:
+                a16, f_saved = _gdn_forward(z32, beta, gamma, False)
+            saved.append((a16_in, z32 if s.has_gdn else None, f_saved))
             dims.append((h, w, oh, ow))
             if s.has_gdn:
-                a16 = _gdn_forward(z32, beta, gamma, False)
+                pass
             elif not last:
                 a16 = z16
             h, w = oh, ow
@@ -188,7 +213,7 @@ class AnalysisFn(torch.autograd.Function):
         for i in reversed(range(len(specs))):
             s = specs[i]
             wt, b, _, _ = layers[i]
-            a16_in, _ = saved[i]
+            a16_in = saved[i][0]
             h, w, oh, ow = dims[i]
             kk = s.ks * s.ks
             gw = torch.empty((kk, s.cin_p, s.cout_p), dtype=torch.float32, device=dev)
@@ -207,9 +232,9 @@ class AnalysisFn(torch.autograd.Function):
             _lib.check(L.cae_t_conv_dgrad_ext(g16.data_ptr(), n, oh, ow, s.cout_p, wp_d.data_ptr(), s.ks, h, w,
                                               gext.data_ptr(), s.cin_p, _st()))
             if specs[i - 1].has_gdn:
-                _, z_prev = saved[i - 1]
+                _, z_prev, f_prev = saved[i - 1]
                 _, _, beta_p, gamma_p = layers[i - 1]
-                g16, g_beta, g_gamma = _gdn_backward(z_prev, gext, P, beta_p, gamma_p, False)
+                g16, g_beta, g_gamma = _gdn_backward(z_prev, gext, P, beta_p, gamma_p, False, f_prev)
                 per_layer[i - 1][2], per_layer[i - 1][3] = g_beta, g_gamma
             else:
                 g16 = torch.empty((n, h, w, s.cin_p), dtype=torch.bfloat16, device=dev)
@@ -248,10 +273,14 @@ class SynthesisFn(torch.autograd.Function):
             z16 = None if need32 else torch.empty((n, 2 * h, 2 * w, s.cout_p), dtype=torch.bfloat16, device=yq.device)
             _lib.check(L.cae_t_deconv_forward(a16.data_ptr(), n, h, w, s.cin_p, wp.data_ptr(), s.ks, _ptr(z32), _ptr(z16),
                                               s.cout_p, _ptr(bias_p), _st()))
-            saved.append((a16, z32 if s.has_gdn else None))
+            f_saved = None
+            a16_in = a16
+            if s.has_gdn:
+                a16, f_saved = _gdn_forward(z32, beta, gamma, True)
+            saved.append((a16_in, z32 if s.has_gdn else None, f_saved))
             dims.append((h, w))
             if s.has_gdn:
-                a16 = _gdn_forward(z32, beta, gamma, True)
+                pass
             elif not last:
                 a16 = z16
             h, w = 2 * h, 2 * w
@@ -273,7 +302,7 @@ class SynthesisFn(torch.autograd.Function):
         for i in reversed(range(len(specs))):
             s = specs[i]
             wt, b, _, _ = layers[i]
-            a16_in, _ = saved[i]
+            a16_in = saved[i][0]
             h, w = dims[i]
             kk = s.ks * s.ks
             gw = torch.empty((kk, s.cout_p, s.cin_p), dtype=torch.float32, device=dev)
@@ -296,9 +325,9 @@ class SynthesisFn(torch.autograd.Function):
             if i == 0:
                 g_in = _to_nchw(gx32, s.cin)
             elif prev_gdn:
-                _, z_prev = saved[i - 1]
+                _, z_prev, f_prev = saved[i - 1]
                 _, _, beta_p, gamma_p = layers[i - 1]
-                g16, g_beta, g_gamma = _gdn_backward(z_prev, gx32, 0, beta_p, gamma_p, True)
+                g16, g_beta, g_gamma = _gdn_backward(z_prev, gx32, 0, beta_p, gamma_p, True, f_prev)
                 per_layer[i - 1][2], per_layer[i - 1][3] = g_beta, g_gamma
             else:
                 g16 = gx16

@@ -123,11 +123,17 @@ def test_deconv_kernels(cae, cin, cout, ks, shape):
     assert rel(train._weight_grad(gw, (cin, cout), ks), wt.grad) < 1e-3
 
 
+@pytest.mark.parametrize('fused', [False, True])
 @pytest.mark.parametrize('inverse', [False, True])
-@pytest.mark.parametrize('c,shape,pad', [(128, (2, 19, 23), 1), (48, (1, 40, 31), 2), (192, (1, 9, 14), 0), (32, (3, 8, 8), 1)])
-def test_gdn_kernels(cae, inverse, c, shape, pad):
-    """fp32 GDN / IGDN forward and backward (with the reflect fold of an extended-domain gradient) against autograd."""
+@pytest.mark.parametrize('c,shape,pad', [(128, (2, 19, 23), 1), (48, (1, 40, 31), 2), (192, (1, 9, 14), 0), (32, (3, 8, 8), 1),
+                                         (96, (2, 33, 17), 2), (128, (4, 64, 64), 0)])
+def test_gdn_kernels(cae, inverse, c, shape, pad, fused, monkeypatch):
+    """fp32 GDN / IGDN forward and backward (with the reflect fold of an extended-domain gradient) against autograd:
+    the three-kernel form and the fused pair (forward saving its factor, one-kernel backward; up to 128 channels)."""
     from cnn_autoencoder_amd import _lib, train
+    if fused and train._pad32(c) > 128:
+        pytest.skip('the fused kernels are built for at most 128 channels')
+    monkeypatch.setenv('CAE_GDN_FUSED', '1' if fused else '0')
     L = _lib.lib()
     torch.manual_seed(c + pad)
     n, h, w = shape
@@ -155,7 +161,11 @@ def test_gdn_kernels(cae, inverse, c, shape, pad):
     assert rel(from_t(y32, c), y.detach()) < 1e-4
     assert rel(from_t(y16, c), y.detach()) < 1e-2
     ge = to_t(gext, cp, torch.float32)
-    gz16, gb, gg = train._gdn_backward(z32, ge, pad, beta_d, gamma_d, inverse)
+    f = None
+    if fused:
+        y16, f = train._gdn_forward(z32, beta_d, gamma_d, inverse)
+        assert f is not None and rel(from_t(y16, c), y.detach()) < 1e-2
+    gz16, gb, gg = train._gdn_backward(z32, ge, pad, beta_d, gamma_d, inverse, f)
     assert rel(from_t(gz16, c), z.grad) < 1e-2  # (stored as bf16)
     assert rel(gb[:c], beta.grad) < 1e-4
     assert rel(gg[:c, :c], gamma.grad) < 1e-4
