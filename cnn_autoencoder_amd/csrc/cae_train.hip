@@ -447,7 +447,7 @@ int cae_t_gdn_forward_save(const float *z32, long pixels, int cp, const float *b
     return launch_gdn_fused(a, cp, false, (hipStream_t)stream);
 }
 
-int cae_t_gdn_backward_fused(const float *z32, const float *f_saved, const float *gext32, int n, int h, int w, int pad, int cp,
+int cae_t_gdn_backward_fused(const float *z32, const float *f_saved, float *gext32, int n, int h, int w, int pad, int cp,
                              const float *gamma, int inverse, void *gz16, float *ggamma, float *gbeta, void *stream) {
     if (!z32 || !f_saved || !gext32 || !gamma || !gz16 || !ggamma || !gbeta) return fail(CAE_ERR_ARG, "NULL argument");
     if (n < 1 || h < 1 || w < 1 || pad < 0 || cp % 32) return fail(CAE_ERR_ARG, "bad shape");
@@ -457,6 +457,10 @@ int cae_t_gdn_backward_fused(const float *z32, const float *f_saved, const float
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(ggamma, 0, (size_t)cp * cp * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(gbeta, 0, (size_t)cp * sizeof(float), st));
+    if (pad > 0) {  // reflect fold of the extended-domain gradient, in place (touches the border pixels only)
+        hipLaunchKernelGGL(fold_inplace_kernel, dim3((unsigned)(n * h)), dim3(256), 0, st, gext32, h, w, pad, cp);
+        HIP_TRY(hipGetLastError());
+    }
     GdnFusedArgs a{};
     a.z = z32;
     a.gamma = gamma;

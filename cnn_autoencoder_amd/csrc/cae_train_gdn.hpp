@@ -25,6 +25,10 @@
 #pragma once
 #include "cae_train_kernels.hpp"
 
+#ifndef GDN_ABL
+#define GDN_ABL 0  // timing experiments (profiles/r03_experiments.md): bit 0 no Gamma^T g_n loop, 1 no g_Gamma loop,
+#endif             // 2 no staging after the first tile, 3 no output stores, 4 no element-wise 1 -- results are wrong
+
 namespace cae {
 namespace tr {
 
@@ -34,7 +38,7 @@ struct GdnFusedArgs {
     const float *beta;    // forward: [C] (effective)
     float *f;             // saved factor, register order (see above): forward writes, backward reads
     void *y16;            // forward: y bf16 [pixels][C]
-    FoldSrc gy;           // backward: gradient w.r.t. y, fp32, extended domain with padding gy.P (0: plain)
+    FoldSrc gy;           // backward: gradient w.r.t. y, fp32, extended domain with padding gy.P, ALREADY folded in place
     int img_h, img_w;     // backward: pixel index -> (n, y, x)
     void *gz16;           // backward: g_z bf16 [pixels][C]
     float *ggamma, *gbeta;  // backward: [C][C], [C], zeroed by the caller
@@ -42,10 +46,40 @@ struct GdnFusedArgs {
     int inverse;
 };
 
+// Block barrier that publishes this wave's LDS writes WITHOUT waiting for vector memory: __syncthreads() compiles to
+// `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`, i.e. a barrier after the prefetch has been issued waits for the whole
+// prefetch -- the first form of these kernels ran at exactly MFMA time + memory time (profiles/r03_experiments.md).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Reflect fold of an extended-domain gradient IN PLACE: every interior pixel next to the border collects the values its
+// mirror images in the padding ring hold (fold_read's sum; the sources lie in the ring and are never written).  One block
+// per (sample, row); lanes over channels.  Afterwards the interior of g is the gradient with respect to the unpadded
+// tensor and consumers read it with a plain offset.
+static __global__ void fold_inplace_kernel(float *g, int H, int W, int P, int C) {
+    const int n = blockIdx.x / H, y = blockIdx.x - n * H;
+    const int HP = H + 2 * P, WP = W + 2 * P;
+    const bool row_folds = (y >= 1 && y <= P) || (y <= H - 2 && y >= H - 1 - P);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const FoldSrc f{g, H, W, P};
+    for (int x = wave; x < W; x += nw) {
+        const bool col_folds = (x >= 1 && x <= P) || (x <= W - 2 && x >= W - 1 - P);
+        if (!row_folds && !col_folds) continue;
+        float *dst = g + (((size_t)n * HP + y + P) * WP + x + P) * C;
+        for (int c = lane; c < C; c += 64) dst[c] = fold_read(f, n, y, x, C, c);
+    }
+}
+
 // byte offset of 16-byte piece `s` of tile pixel `p` in a staged fp32 tile of C channels
+// (LDS serves a ds_read_b128 sixteen lanes at a time: sixteen consecutive pixels reading the same piece must hit sixteen
+// different 16-byte bank groups.  Rows of a multiple of 256 bytes all start in the same group -> XOR the low 4 bits of the
+// pixel into the slot; 128-byte rows alternate between the two halves of the banks by themselves -> 3 bits of p >> 1.)
+template <int C>
+__device__ __forceinline__ int gdn_swz(int p, int s) {
+    return (C % 64 == 0) ? (s ^ (p & 15)) : ((s & ~7) | ((s & 7) ^ ((p >> 1) & 7)));
+}
 template <int C>
 __device__ __forceinline__ int gdn_slot(int p, int s) {
-    return p * (C * 4) + ((s & ~7) | ((s & 7) ^ ((p >> 1) & 7))) * 16;
+    return p * (C * 4) + gdn_swz<C>(p, s) * 16;
 }
 
 // LDS-DMA of `PT` pixel rows (fp32, C channels) starting at tile pixel 0 = global pixel pix0; src_of(pixel) -> row address.
@@ -59,7 +93,7 @@ __device__ __forceinline__ void gdn_stage(char *buf, int wave, int lane, long pi
         if (INSTR % NW == 0 || j < INSTR) {
             const int byte = j * 1024 + lane * 16;
             const int p = byte / (C * 4), slot = (byte % (C * 4)) >> 4;
-            const int s = (slot & ~7) | ((slot & 7) ^ ((p >> 1) & 7));  // the piece whose swizzled slot this lane fills
+            const int s = gdn_swz<C>(p, slot);  // the piece whose swizzled slot this lane fills (the XOR is an involution)
             long gp = pix0 + p;
             gp = gp < pixels ? gp : pixels - 1;  // clamped rows are computed and never stored / masked
             glds16(src_of(gp) + s * 16, buf + j * 1024);
@@ -93,61 +127,93 @@ __global__ void __launch_bounds__(CT * 64, 1) gdn_fwd_fused_kernel(const GdnFuse
     gdn_load_gamma<C>(mlds, p.gamma, threadIdx.x, CT * 64);
     const long tiles = (p.pixels + PT - 1) / PT;
     auto zrow = [&](long gp) { return (const char *)(p.z + gp * C); };
-    long tile = blockIdx.x;
+    // The previous tile's outputs leave at the TOP of an iteration, before the next prefetch is issued: vmcnt counts loads
+    // and stores alike, and a store issued after the prefetch would make the wait for that prefetch a wait for the store's
+    // round trip to L2 as well (measured: the kernel ran at 0.45 of the fp32 MFMA peak with the stores at the bottom).
+    auto copy_out = [&](long t) {
+        for (int i = threadIdx.x; i < PT * (C / 8); i += CT * 64) {
+            const int px = i / (C / 8), part = i - px * (C / 8);
+            const long gp = t * PT + px;
+            if (gp < p.pixels)
+                *(f32x4 *)((char *)p.y16 + (gp * C) * 2 + part * 16) = *(const f32x4 *)(ybuf + px * YS + part * 16);
+        }
+    };
+    f32x4 fkeep[2][4];  // the factors of the previous tile, stored one iteration later for the same reason
+    auto store_f = [&](long t) {
+        static_for<2>([&](auto pt_tag) {
+            constexpr int pt = decltype(pt_tag)::value;
+            static_for<4>([&](auto g_tag) {
+                constexpr int g = decltype(g_tag)::value;
+                *(f32x4 *)(p.f + ((((t * 2 + pt) * CT + wave) * 4 + g) * 64 + lane) * 4) = fkeep[pt][g];
+            });
+        });
+    };
+    float bet[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bet[r] = p.beta[32 * wave + acc_row(r) + 4 * h];
+    long tile = blockIdx.x, prev = -1;
     if (tile < tiles) gdn_stage<C, PT, CT>(zbuf, wave, lane, tile * PT, p.pixels, zrow);
-    for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
+    for (int it = 0; tile < tiles; prev = tile, tile += gridDim.x, ++it) {
         char *cur = zbuf + (it & 1) * Z_BYTES;
         wait_vm0();
-        __syncthreads();  // this tile landed; the other buffer and ybuf are free
+        __syncthreads();  // this tile landed; the previous tile's output image is complete; the other z buffer is free
+        if (prev >= 0) {
+            copy_out(prev);
+            store_f(prev);
+        }
         if (tile + gridDim.x < tiles)
             gdn_stage<C, PT, CT>(zbuf + ((it + 1) & 1) * Z_BYTES, wave, lane, (tile + gridDim.x) * PT, p.pixels, zrow);
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float b = p.beta[32 * wave + acc_row(r) + 4 * h];
-            acc[0][r] = b;
-            acc[1][r] = b;
+            acc[0][r] = bet[r];
+            acc[1][r] = bet[r];
         }
-        // n[c][pix] = beta[c] + sum_j Gamma[c][j] z[pix][j]^2 :  A = Gamma rows of this wave's tile, B = z^2 (lane = pixel)
-#pragma unroll 4
-        for (int q = 0; q < C / 8; ++q) {
-            const f32x4 mf = *(const f32x4 *)(mlds + (32 * wave + m) * LD + 8 * q + 4 * h);
-            f32x4 v0 = *(const f32x4 *)(cur + gdn_slot<C>(m, 2 * q + h));
-            f32x4 v1 = *(const f32x4 *)(cur + gdn_slot<C>(32 + m, 2 * q + h));
-            v0 *= v0;
-            v1 *= v1;
+        // n[c][pix] = beta[c] + sum_j Gamma[c][j] z[pix][j]^2 :  A = Gamma rows of this wave's tile, B = z^2 (lane = pixel);
+        // the operands of step q + 1 are read while the MFMAs of step q run
+        {
+            f32x4 mf[2], v0[2], v1[2];
+            auto fetch = [&](int q, int k) {
+                mf[k] = *(const f32x4 *)(mlds + (32 * wave + m) * LD + 8 * q + 4 * h);
+                v0[k] = *(const f32x4 *)(cur + gdn_slot<C>(m, 2 * q + h));
+                v1[k] = *(const f32x4 *)(cur + gdn_slot<C>(32 + m, 2 * q + h));
+            };
+            fetch(0, 0);
+            static_for<C / 8>([&](auto q_tag) {
+                constexpr int q = decltype(q_tag)::value, k = q & 1;
+                if (q + 1 < C / 8) fetch(q + 1, k ^ 1);
+                v0[k] *= v0[k];
+                v1[k] *= v1[k];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[s], v0[s], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[s], v1[s], acc[1], 0, 0, 0);
-            }
+                for (int s = 0; s < 4; ++s) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[k][s], v0[k][s], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[k][s], v1[k][s], acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
+        lds_barrier();  // the copy-out of the previous tile has read the output image (no wait for the prefetch)
         // element-wise on the wave's own channels: run g = channels 32 wave + 8 g + 4 h .. + 3 of pixel 32 pt + m
         static_for<2>([&](auto pt_tag) {
             constexpr int pt = decltype(pt_tag)::value;
-            const long tile32 = tile * 2 + pt;
             static_for<4>([&](auto g_tag) {
                 constexpr int g = decltype(g_tag)::value;
                 const f32x4 zz = *(const f32x4 *)(cur + gdn_slot<C>(32 * pt + m, 8 * wave + 2 * g + h));
-                f32x4 f;
                 bf16x4 y;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float d = acc[pt][4 * g + k];
-                    f[k] = p.inverse ? __builtin_amdgcn_sqrtf(d) : __builtin_amdgcn_rsqf(d);
-                    y[k] = (__bf16)(zz[k] * f[k]);
+                    fkeep[pt][g][k] = p.inverse ? __builtin_amdgcn_sqrtf(d) : __builtin_amdgcn_rsqf(d);
+                    y[k] = (__bf16)(zz[k] * fkeep[pt][g][k]);
                 }
-                *(f32x4 *)(p.f + (((tile32 * CT + wave) * 4 + g) * 64 + lane) * 4) = f;
                 *(bf16x4 *)(ybuf + (32 * pt + m) * YS + (32 * wave + 8 * g + 4 * h) * 2) = y;
             });
         });
-        __syncthreads();  // the output image is complete
-        for (int i = threadIdx.x; i < PT * (C / 8); i += CT * 64) {
-            const int px = i / (C / 8), part = i - px * (C / 8);
-            const long gp = tile * PT + px;
-            if (gp < p.pixels)
-                *(f32x4 *)((char *)p.y16 + (gp * C) * 2 + part * 16) = *(const f32x4 *)(ybuf + px * YS + part * 16);
-        }
+    }
+    __syncthreads();
+    if (prev >= 0) {
+        copy_out(prev);
+        store_f(prev);
     }
 }
 
@@ -169,43 +235,51 @@ __global__ void __launch_bounds__(CT * 64, 1) gdn_bwd_fused_kernel(const GdnFuse
     gdn_load_gamma<C>(mlds, p.gamma, threadIdx.x, CT * 64);
     const int P = p.gy.P, HP = p.img_h + 2 * P, WP = p.img_w + 2 * P;
     const unsigned hw = (unsigned)(p.img_h * p.img_w);
+    const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)p.img_w;
     auto zrow = [&](long gp) { return (const char *)(p.z + gp * C); };
+    // pixel index -> (n, y, x) by float reciprocal + one correction step (quotients stay far below 2^23; an integer
+    // division costs ~40 vector instructions and a thread needs sixteen per tile)
+    auto fdiv = [](unsigned u, unsigned d, float inv, unsigned &q, unsigned &r) {
+        q = (unsigned)((float)u * inv);
+        int rr = (int)(u - q * d);
+        if (rr < 0) {
+            --q;
+            rr += (int)d;
+        } else if (rr >= (int)d) {
+            ++q;
+            rr -= (int)d;
+        }
+        r = (unsigned)rr;
+    };
     auto split = [&](long gp, int &n, int &y, int &x) {
-        const unsigned u = (unsigned)gp;
-        n = (int)(u / hw);
-        const unsigned rem = u - (unsigned)n * hw;
-        y = (int)(rem / (unsigned)p.img_w);
-        x = (int)(rem - (unsigned)y * (unsigned)p.img_w);
+        unsigned q, r, yy, xx;
+        fdiv((unsigned)gp, hw, inv_hw, q, r);
+        fdiv(r, (unsigned)p.img_w, inv_w, yy, xx);
+        n = (int)q;
+        y = (int)yy;
+        x = (int)xx;
     };
     auto grow = [&](long gp) {  // the pixel's own row in the extended-domain gradient
+        if (P == 0) return (const char *)(p.gy.g + gp * C);
         int n, y, x;
         split(gp, n, y, x);
         return (const char *)(p.gy.g + (((size_t)n * HP + y + P) * WP + x + P) * C);
     };
-    // reflect fold (P > 0): pixels next to the border also collect the gradient of their mirror images in the padding
-    // ring; the lane that staged a piece of such a pixel rewrites it with the folded sum before the tile is published
-    auto fold_fix = [&](char *buf, long pix0) {
-        constexpr int INSTR = PT * C * 4 / 1024;
-#pragma unroll
-        for (int i = 0; i < (INSTR + CT - 1) / CT; ++i) {
-            const int j = wave + CT * i;
-            if (INSTR % CT == 0 || j < INSTR) {
-                const int byte = j * 1024 + lane * 16;
-                const int px = byte / (C * 4), slot = (byte % (C * 4)) >> 4;
-                const int s = (slot & ~7) | ((slot & 7) ^ ((px >> 1) & 7));
-                long gp = pix0 + px;
-                gp = gp < p.pixels ? gp : p.pixels - 1;
-                int n, y, x;
-                split(gp, n, y, x);
-                const bool interior = y > P && y < p.img_h - 1 - P && x > P && x < p.img_w - 1 - P;
-                if (!interior) {
-                    f32x4 v;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = fold_read(p.gy, n, y, x, C, 4 * s + k);
-                    *(f32x4 *)(buf + byte) = v;
-                }
-            }
+    // (as in the forward kernel: the previous tile's output leaves at the top of an iteration, before the next prefetch)
+    auto copy_out = [&](long t) {
+        for (int i = threadIdx.x; i < PT * (C / 8); i += CT * 64) {
+            const int px = i / (C / 8), part = i - px * (C / 8);
+            const long gp = t * PT + px;
+            if (gp < p.pixels)
+                *(f32x4 *)((char *)p.gz16 + (gp * C) * 2 + part * 16) = *(const f32x4 *)(obuf + px * OS + part * 16);
         }
+    };
+    f32x4 fnext[4];  // the saved factors of the NEXT tile, loaded a tile ahead beside the LDS-DMA prefetch
+    auto load_f = [&](long t) {
+        static_for<4>([&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            fnext[g] = *(const f32x4 *)(p.f + (((t * CT + wave) * 4 + g) * 64 + lane) * 4);
+        });
     };
 
     f32x16 accg[CT];  // g_Gamma[32 wave + row][32 jt + lane]
@@ -216,52 +290,74 @@ __global__ void __launch_bounds__(CT * 64, 1) gdn_bwd_fused_kernel(const GdnFuse
     float bsum = 0.0f;
 
     const long tiles = (p.pixels + PT - 1) / PT;
-    long tile = blockIdx.x;
+    long tile = blockIdx.x, prev = -1;
     if (tile < tiles) {
         gdn_stage<C, PT, CT>(zbuf, wave, lane, tile * PT, p.pixels, zrow);
         gdn_stage<C, PT, CT>(gbuf, wave, lane, tile * PT, p.pixels, grow);
+        load_f(tile);
     }
-    for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
+    for (int it = 0; tile < tiles; prev = tile, tile += gridDim.x, ++it) {
         char *zc = zbuf + (it & 1) * T_BYTES, *gc = gbuf + (it & 1) * T_BYTES;
         wait_vm0();
-        if (P > 0) fold_fix(gc, tile * PT);
-        __syncthreads();  // both tiles landed (and folded); the other buffers and obuf are free
-        if (tile + gridDim.x < tiles) {
+        f32x4 f[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) f[g] = fnext[g];
+        __syncthreads();  // both tiles landed; the previous output image is complete; the other buffers are free
+        if (prev >= 0 && !(GDN_ABL & 8)) copy_out(prev);
+        if (tile + gridDim.x < tiles && !(GDN_ABL & 4)) {
             gdn_stage<C, PT, CT>(zbuf + ((it + 1) & 1) * T_BYTES, wave, lane, (tile + gridDim.x) * PT, p.pixels, zrow);
             gdn_stage<C, PT, CT>(gbuf + ((it + 1) & 1) * T_BYTES, wave, lane, (tile + gridDim.x) * PT, p.pixels, grow);
+            load_f(tile + gridDim.x);
         }
         // element-wise 1 on the wave's own channels of pixel m: g_n (back into the g_y tile), direct term, z kept
         const bool valid = tile * PT + m < p.pixels;  // pixels past the end contribute nothing to the parameter gradients
         f32x4 zz[4], gzd[4];
-        static_for<4>([&](auto g_tag) {
+        if (GDN_ABL & 16)
+            for (int g = 0; g < 4; ++g) zz[g] = gzd[g] = f[g];
+        if (!(GDN_ABL & 16)) static_for<4>([&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
             const int off = gdn_slot<C>(m, 8 * wave + 2 * g + h);
             zz[g] = *(const f32x4 *)(zc + off);
             const f32x4 gy = *(const f32x4 *)(gc + off);
-            const f32x4 f = *(const f32x4 *)(p.f + (((tile * CT + wave) * 4 + g) * 64 + lane) * 4);
             f32x4 gn;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                gzd[g][k] = gy[k] * f[k];
-                const float v = p.inverse ? 0.5f * gy[k] * zz[g][k] * __builtin_amdgcn_rcpf(f[k])
-                                          : -0.5f * gy[k] * zz[g][k] * f[k] * f[k] * f[k];
+                gzd[g][k] = gy[k] * f[g][k];
+                const float v = p.inverse ? 0.5f * gy[k] * zz[g][k] * __builtin_amdgcn_rcpf(f[g][k])
+                                          : -0.5f * gy[k] * zz[g][k] * f[g][k] * f[g][k] * f[g][k];
                 gn[k] = valid ? v : 0.0f;
             }
             *(f32x4 *)(gc + off) = gn;
         });
-        __syncthreads();  // g_n of every channel is in place
-        // t[j][pix] = sum_c Gamma[c][j] g_n[c][pix] :  A = Gamma^T rows j of this wave's tile (column reads), B = g_n
-        f32x16 t;
+        lds_barrier();  // g_n of every channel is in place; the copy-out has read the output image
+        // t[j][pix] = sum_c Gamma[c][j] g_n[c][pix] :  A = Gamma^T rows j of this wave's tile (column reads), B = g_n.
+        // Operands of step q + 1 are read while the MFMAs of step q run (registers: the compiler's own schedule waited for
+        // every LDS read right before its MFMA pair); two accumulators break the dependent chain.
+        f32x16 t, t1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t[r] = 0.0f;
-#pragma unroll 4
-        for (int q = 0; q < C / 8; ++q) {
-            const f32x4 vb = *(const f32x4 *)(gc + gdn_slot<C>(m, 2 * q + h));
+        for (int r = 0; r < 16; ++r) t[r] = t1[r] = 0.0f;
+        {
+            constexpr int NQ = (GDN_ABL & 1) ? 0 : C / 8;
+            f32x4 vb[2];
+            float a[2][4];
+            auto fetch = [&](int q, int k) {
+                vb[k] = *(const f32x4 *)(gc + gdn_slot<C>(m, 2 * q + h));
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float a = mlds[(8 * q + 4 * h + s) * LD + 32 * wave + m];
-                t = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vb[s], t, 0, 0, 0);
-            }
+                for (int s = 0; s < 4; ++s) a[k][s] = mlds[(8 * q + 4 * h + s) * LD + 32 * wave + m];
+            };
+            if (NQ) fetch(0, 0);
+            static_for<NQ>([&](auto q_tag) {
+                constexpr int q = decltype(q_tag)::value;
+                if (q + 1 < NQ) fetch(q + 1, (q + 1) & 1);
+#pragma unroll
+                for (int s = 0; s < 4; s += 2) {
+                    t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][s], vb[q & 1][s], t, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][s + 1], vb[q & 1][s + 1], t1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] += t1[r];
         }
         static_for<4>([&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
@@ -270,27 +366,32 @@ __global__ void __launch_bounds__(CT * 64, 1) gdn_bwd_fused_kernel(const GdnFuse
             for (int k = 0; k < 4; ++k) o[k] = (__bf16)(gzd[g][k] + 2.0f * zz[g][k] * t[4 * g + k]);
             *(bf16x4 *)(obuf + m * OS + (32 * wave + 8 * g + 4 * h) * 2) = o;
         });
-        // g_Gamma[c][j] += sum_pix g_n[c][pix] z[pix][j]^2 : channel on the lane, pixels 2 s + h on the k index
-#pragma unroll 4
-        for (int s = 0; s < PT / 2; ++s) {
-            const int px = 2 * s + h;
-            const float a = *(const float *)(gc + gdn_slot<C>(px, 8 * wave + (m >> 2)) + (m & 3) * 4);
-            bsum += a;
+        // g_Gamma[c][j] += sum_pix g_n[c][pix] z[pix][j]^2 : channel on the lane, two pixels per k-step.  The pair of a
+        // step is (px, px + 8): with the tile's swizzle the two lane halves then read different banks.
+        {
+            constexpr int NS = (GDN_ABL & 2) ? 0 : PT / 2;
+            float a[2], b[2][CT];
+            auto fetch = [&](int s, int k) {
+                const int px = (s & 7) + 16 * (s >> 3) + 8 * h;
+                a[k] = *(const float *)(gc + gdn_slot<C>(px, 8 * wave + (m >> 2)) + (m & 3) * 4);
 #pragma unroll
-            for (int jt = 0; jt < CT; ++jt) {
-                float b = *(const float *)(zc + gdn_slot<C>(px, 8 * jt + (m >> 2)) + (m & 3) * 4);
-                b *= b;
-                accg[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accg[jt], 0, 0, 0);
-            }
-        }
-        __syncthreads();  // the output image is complete
-        for (int i = threadIdx.x; i < PT * (C / 8); i += CT * 64) {
-            const int px = i / (C / 8), part = i - px * (C / 8);
-            const long gp = tile * PT + px;
-            if (gp < p.pixels)
-                *(f32x4 *)((char *)p.gz16 + (gp * C) * 2 + part * 16) = *(const f32x4 *)(obuf + px * OS + part * 16);
+                for (int jt = 0; jt < CT; ++jt)
+                    b[k][jt] = *(const float *)(zc + gdn_slot<C>(px, 8 * jt + (m >> 2)) + (m & 3) * 4);
+            };
+            if (NS) fetch(0, 0);
+            static_for<NS>([&](auto s_tag) {
+                constexpr int s = decltype(s_tag)::value;
+                if (s + 1 < NS) fetch(s + 1, (s + 1) & 1);
+                bsum += a[s & 1];
+#pragma unroll
+                for (int jt = 0; jt < CT; ++jt)
+                    accg[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1], b[s & 1][jt] * b[s & 1][jt], accg[jt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
     }
+    __syncthreads();
+    if (prev >= 0) copy_out(prev);
     // D: register r = channel 32 wave + acc_row(r) + 4h, lane = j
 #pragma unroll
     for (int jt = 0; jt < CT; ++jt)

@@ -287,11 +287,12 @@ int cae_t_gdn_backward(const float *z32, const float *gext32, int n, int h, int 
 /* Fused forms (csrc/cae_train_gdn.hpp; cp <= 128): the forward also saves the per-element factor f (y = z f: n^(-1/2),
  * IGDN n^(1/2)) in the register order the backward reads back -- f_saved holds cae_t_gdn_saved_elems(pixels, cp) floats
  * (0: shape not built) -- and the backward is ONE kernel: g_z (bf16), g_gamma, g_beta from z, f and the gradient with
- * respect to y (extended domain with padding `pad`, folded inside), without recomputing the norm. */
+ * respect to y (extended domain with padding `pad`; its reflect fold is applied to gext32 IN PLACE first), without
+ * recomputing the norm. */
 size_t cae_t_gdn_saved_elems(long pixels, int cp);
 int cae_t_gdn_forward_save(const float *z32, long pixels, int cp, const float *beta, const float *gamma, int inverse,
                            void *y16, float *f_saved, void *stream);
-int cae_t_gdn_backward_fused(const float *z32, const float *f_saved, const float *gext32, int n, int h, int w, int pad, int cp,
+int cae_t_gdn_backward_fused(const float *z32, const float *f_saved, float *gext32 /* folded in place */, int n, int h, int w, int pad, int cp,
                              const float *gamma, int inverse, void *gz16, float *ggamma, float *gbeta, void *stream);
 int cae_t_fold_to_bf16(const float *gext32, int n, int h, int w, int pad, int cp, void *out16, void *stream);
 int cae_t_colsum(const void *g16, long pixels, int cp, float *out, void *stream); /* bias gradient */
