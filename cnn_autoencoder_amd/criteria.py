@@ -84,3 +84,22 @@ class GeneralLoss(nn.Module):
             loss_dict['entropy_loss'] = getattr(fe, 'module', fe).loss()
             loss_dict['loss'] = loss_dict['loss'] + loss_dict['rate_loss']
         return loss_dict
+
+
+def setup_loss(criterion: str, **kwargs) -> GeneralLoss:
+    """``models/criteria/_lossutils.py:112-151``: the criterion NAME selects the terms ('RateMSE' = the reference's
+    default, ``utils/args/_critargs.py:42``).  Built: the Rate term and the MSE distortion; the names of the terms outside
+    the compression path (MS-SSIM / multiscale distortions, penalties, classification losses) raise."""
+    name = criterion.lower()
+    rate = 'Rate' if 'rate' in name else None
+    if 'mse' in name:
+        dist = 'MSE'
+    elif 'msssim' in name or 'ms-ssim' in name:
+        raise NotImplementedError('the MS-SSIM distortion is outside the compression hot path')
+    else:
+        dist = None
+    # (the reference tests `'pa' in name` / `'ce' in name` as plain substrings; those terms are not built here)
+    for key in ('multiscale', 'penalty', 'crossentropy', 'bce', 'weighted'):
+        if key in name:
+            raise NotImplementedError(f'criterion {criterion!r}: the {key} term is outside the compression hot path')
+    return GeneralLoss(dist, rate, 'none', None, **kwargs)

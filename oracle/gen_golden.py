@@ -187,6 +187,64 @@ def make_init_fixture(ref):
     print('ref_init_seed0', list(out.keys()))
 
 
+def load_reference_criteria():
+    """The reference's loss classes (src/models/criteria/_ratedist.py, _lossutils.py, _classification.py) loaded by
+    file path as a throw-away package; pytorch_msssim (absent from this image, only used by the MS-SSIM distortions)
+    is stubbed exactly as compressai is for _autoencoders.py."""
+    base = '/root/reference/src/models/criteria'
+    stub = types.ModuleType('pytorch_msssim')
+    stub.ms_ssim = None
+    sys.modules['pytorch_msssim'] = stub
+    pkg = types.ModuleType('refcrit')
+    pkg.__path__ = [base]
+    sys.modules['refcrit'] = pkg
+    mods = {}
+    for name in ('_ratedist', '_classification', '_lossutils'):
+        spec = importlib.util.spec_from_file_location(f'refcrit.{name}', os.path.join(base, name + '.py'))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f'refcrit.{name}'] = mod
+        spec.loader.exec_module(mod)
+        mods[name] = mod
+    return mods
+
+
+def make_loss_case():
+    """Values of the reference's training objective (GeneralLoss via setup_loss('RateMSE'), RateLoss, DistMSELoss;
+    _lossutils.py:5-109, _ratedist.py:45-63) on seeded tensors -> tests/golden/ref_loss_ratemse.npz.  `entropy_loss`
+    is whatever net['fact_ent'].module.loss() returns: a stand-in module hands back a fixed tensor."""
+    crit = load_reference_criteria()
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(3, 3, 40, 56, generator=g)
+    x_r = (x + 0.05 * torch.randn(3, 3, 40, 56, generator=g)).clamp(0, 1)
+    p_y = torch.rand(3, 24, 5, 7, generator=g).clamp_min(1e-9)
+    aux = torch.tensor(12.375)
+
+    class _Fe:
+        def loss(self):
+            return aux
+
+    class _Wrapped:
+        module = _Fe()
+
+    out = {}
+    for lam in (0.01, 0.1):
+        crit_obj = crit['_lossutils'].setup_loss('RateMSE', distortion_lambda=lam)
+        ld = crit_obj(inputs=x, outputs=dict(x_r=[x_r, None], p_y=p_y, y=None), net={'fact_ent': _Wrapped()})
+        tag = str(lam).replace('.', 'p')
+        out[f'loss_{tag}'] = np.float64(float(ld['loss']))
+        out[f'dist_loss_{tag}'] = np.float64(float(ld['dist_loss']))
+        out[f'dist0_{tag}'] = np.float64(float(ld['dist'][0]))
+        out[f'rate_loss_{tag}'] = np.float64(float(ld['rate_loss']))
+        out[f'entropy_loss_{tag}'] = np.float64(float(ld['entropy_loss']))
+        assert sorted(ld.keys()) == ['channel_e', 'dist', 'dist_loss', 'entropy_loss', 'loss', 'rate_loss'], sorted(ld.keys())
+    rate = crit['_ratedist'].RateLoss()(x=x, p_y=p_y)['rate_loss']
+    mse = crit['_ratedist'].DistMSELoss()(x=x, x_r=[x_r])['dist'][0]
+    np.savez_compressed(os.path.join(GOLD, 'ref_loss_ratemse.npz'), x=x.numpy(), x_r=x_r.numpy(), p_y=p_y.numpy(),
+                        aux=np.float64(float(aux)), rate_only=np.float64(float(rate)), mse_only=np.float64(float(mse)),
+                        keys_json=np.frombuffer(json.dumps(sorted(ld.keys())).encode(), dtype=np.uint8), **out)
+    print('ref_loss_ratemse:', {k: float(v) for k, v in out.items()})
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = load_reference()
@@ -243,4 +301,8 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'loss':
+        make_loss_case()  # (only the loss fixture; the model fixtures are unchanged)
+    else:
+        main()
+        make_loss_case()

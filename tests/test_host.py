@@ -499,3 +499,36 @@ def test_likelihood_forms_agree_except_where_float_rounding_decides(cae):
     assert 0 < differing_rows <= 10, f'{differing_rows} of 192 CDF rows differ between the two forms'
     with pytest.raises(ValueError):
         cae.EntropyBottleneck(4, likelihood_form='other')
+
+
+def test_training_objective_matches_the_reference_loss_values():
+    """criteria.GeneralLoss / RateLoss / DistMSELoss / setup_loss against values produced by the REFERENCE's own classes
+    (src/models/criteria/_lossutils.py:5-109, _ratedist.py:45-63; fixture written by `oracle/gen_golden.py loss`), and
+    the oracle's restatement of the same objective (oracle/train_oracle.rd_loss) against both."""
+    import torch
+    from cnn_autoencoder_amd import criteria
+    from oracle import train_oracle as T
+    g = np.load(os.path.join(GOLD, 'ref_loss_ratemse.npz'))
+    x, x_r, p_y = (torch.from_numpy(g[k]) for k in ('x', 'x_r', 'p_y'))
+    aux = torch.tensor(float(g['aux']))
+
+    class _Fe:
+        def loss(self):
+            return aux
+
+    class _Wrapped:
+        module = _Fe()
+
+    assert float(criteria.RateLoss()(x=x, p_y=p_y)['rate_loss']) == pytest.approx(float(g['rate_only']), rel=1e-6)
+    assert float(criteria.DistMSELoss()(x=x, x_r=[x_r])['dist'][0]) == pytest.approx(float(g['mse_only']), rel=1e-6)
+    for lam, tag in ((0.01, '0p01'), (0.1, '0p1')):
+        for crit in (criteria.GeneralLoss(distortion_lambda=lam), criteria.setup_loss('RateMSE', distortion_lambda=lam)):
+            ld = crit(inputs=x, outputs=dict(x_r=[x_r, None], p_y=p_y, y=None), net={'fact_ent': _Wrapped()})
+            assert sorted(ld.keys()) == json.loads(bytes(g['keys_json']).decode())
+            for key in ('loss', 'dist_loss', 'rate_loss', 'entropy_loss'):
+                assert float(ld[key]) == pytest.approx(float(g[f'{key}_{tag}']), rel=1e-6), key
+            assert float(ld['dist'][0]) == pytest.approx(float(g[f'dist0_{tag}']), rel=1e-6)
+        loss_o, dist_o, rate_o = T.rd_loss(x, x_r, p_y, lam)
+        assert float(loss_o) == pytest.approx(float(g[f'loss_{tag}']), rel=1e-6)
+    with pytest.raises(NotImplementedError):
+        criteria.setup_loss('RateMSSSIM')
