@@ -2,6 +2,7 @@
 libcae_hip.so (checked against the oracle), the nn.Module / codec boundary and the slide driver.
 No device entry point is called here (there is no GPU in the build container)."""
 import ctypes
+import json
 import os
 import re
 import struct
