@@ -6,6 +6,7 @@
 #include "cae_train_gdn.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 using namespace cae;
 using namespace cae::tr;
@@ -28,9 +29,9 @@ unsigned ew_grid(size_t total) {
 
 bool bad_channels(int c) { return c < 32 || c % 32 != 0 || c > 192; }
 
-template <int NT>
-int launch_gg_t(const GGArgs &a, size_t lds, hipStream_t st) {
-    auto kern = gather_gemm_kernel<NT>;
+template <int NT, bool PIPE>
+int launch_gg_tp(const GGArgs &a, size_t lds, hipStream_t st) {
+    auto kern = gather_gemm_kernel<NT, PIPE>;
     static size_t attr = 0;
     if (lds > attr) {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -40,6 +41,11 @@ int launch_gg_t(const GGArgs &a, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
     HIP_TRY(hipGetLastError());
     return CAE_OK;
+}
+
+template <int NT>
+int launch_gg_t(const GGArgs &a, size_t lds, hipStream_t st) {
+    return a.nq ? launch_gg_tp<NT, true>(a, lds, st) : launch_gg_tp<NT, false>(a, lds, st);
 }
 
 // fills the halo / staging geometry of `a` from its tap list and launches
@@ -64,7 +70,17 @@ int launch_gg(GGArgs &a, hipStream_t st) {
     const size_t budget = 160 * 1024 - halo;
     a.taps_per_stage = std::min<int>(a.ntaps, (int)(budget / ((size_t)NT * 2048)));
     if (a.taps_per_stage < 1) return fail(CAE_ERR_UNSUPPORTED, "weights of one tap do not fit the LDS");
-    const size_t lds = halo + (size_t)a.taps_per_stage * NT * 2048;
+    size_t lds = halo + (size_t)a.taps_per_stage * NT * 2048;
+    // pipelined form: a slice (32 or 16 channels: halo + the weights of all taps) twice in the LDS
+    a.nq = 0;
+    for (int nq : {4, 2}) {
+        const size_t slice = (size_t)((nq * a.HR * a.HC + 63) / 64) * 1024 + (size_t)a.ntaps * NT * (nq / 2) * 1024;
+        if (2 * slice <= 160 * 1024 && !std::getenv("CAE_GG_LEGACY")) {
+            a.nq = nq;
+            lds = 2 * slice;
+            break;
+        }
+    }
     a.tiles_x = (a.LW + 15) / 16;
     a.tiles_y = (a.LH + 15) / 16;
     a.zero = zero_page();

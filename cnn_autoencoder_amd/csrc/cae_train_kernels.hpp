@@ -23,6 +23,10 @@
 #pragma once
 #include "cae_kernels.hpp"
 
+#ifndef GG_ABL
+#define GG_ABL 0  // timing experiments on gather_gemm (results wrong): bit 0 no MFMA, 1 no LDS-DMA after the first slice,
+#endif            // 2 operand reads from one fixed LDS address, 3 no output stores
+
 namespace cae {
 namespace tr {
 
@@ -73,11 +77,12 @@ struct GGArgs {
     int ntaps, ktaps;   // taps of this launch, taps of the packed weights (KS * KS)
     int dymin, dxmin, HR, HC;
     int taps_per_stage;
+    int nq;             // pipelined form: 8-channel quarters of the contraction per staged slice (4 = a chunk, 2 = half), else 0
     int tiles_x, tiles_y;
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
 };
 
-template <int NT>
+template <int NT, bool PIPE>
 __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -97,13 +102,14 @@ __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
     char *wbuf = smem + (size_t)halo_instr * 1024;
     const char *in_n = (const char *)p.in + (size_t)n * p.IH * p.IW * p.Ck * 2;
 
-    // this thread's halo pieces (same for every chunk): byte offset inside the sample, or -1 = zeros
     constexpr int MAXP = 20;  // ceil(4 * 35 * 35 / 64 / 4)
-    long hoff[MAXP];
+    // this thread's halo pieces (same for every chunk / slice): byte offset inside the sample, or ~0 = zeros
+    const int npieces = PIPE ? p.nq * plane : pieces;
+    unsigned hoff[MAXP];
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         int pc = (wave + i * 4) * 64 + lane;
-        pc = pc < pieces ? pc : pieces - 1;
+        pc = pc < npieces ? pc : npieces - 1;
         const int quarter = pc / plane;
         const int rem = pc - quarter * plane;
         const int r = rem / p.HC, c = rem - r * p.HC;
@@ -115,7 +121,7 @@ __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
         } else {
             ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
         }
-        hoff[i] = ok ? ((long)iy * p.IW + ix) * p.Ck * 2 + quarter * 16 : -1;
+        hoff[i] = ok ? (unsigned)((iy * p.IW + ix) * p.Ck * 2 + quarter * 16) : 0xFFFFFFFFu;
     }
 
     f32x16 acc[2][NT];
@@ -131,6 +137,78 @@ __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
 
     // A operand of m-tile pt: position (4w + 2pt + (m>>4), m&15)
     const int arow = p.S * (4 * wave + (m >> 4)), acol = p.S * (m & 15);
+    if constexpr (PIPE) {
+        // PIPELINED: the contraction is walked in slices of nq quarters (32 or 16 channels); a slice = its halo + the
+        // weights of ALL taps, double-buffered: slice sl + 1 is on its way by LDS-DMA while the MFMAs of slice sl run,
+        // one barrier per slice.  (The first form loaded a chunk, waited, consumed it: MFMA pipes busy 0.09 of the time.)
+        const int nq = p.nq, ksteps = nq / 2, per_chunk = 4 / nq;
+        const int qplane = plane;
+        const int hpieces = nq * qplane, h_instr = (hpieces + 63) / 64;
+        const int w_instr = p.ntaps * NT * ksteps;
+        const size_t buf_bytes = (size_t)(h_instr + w_instr) * 1024;
+        const int slices = p.Ck / (8 * nq);
+        // this thread's weight pieces of a slice, relative to the slice's first k-step: [tap][nt][k-step of the slice]
+        constexpr int MAXW = 10;  // ceil(9 taps * 4 tiles * 2 k-steps / 4 waves / 2) .. more taps: the loop below
+        unsigned woff[MAXW];
+#pragma unroll
+        for (int i = 0; i < MAXW; ++i) {
+            int f = wave + 4 * i;
+            f = f < w_instr ? f : w_instr - 1;
+            const int tl = f / (NT * ksteps), rest = f - tl * (NT * ksteps);
+            const int nt = rest / ksteps, s = rest - nt * ksteps;
+            woff[i] = (unsigned)(((p.wt[tl] * (NT * 2) + nt * 2 + s) * 1024) + lane * 16);
+        }
+        const unsigned chunk_bytes = (unsigned)p.ktaps * (NT * 2) * 1024;
+        auto issue = [&](int sl, char *buf) {
+            const int q = sl / per_chunk, s0 = (sl - q * per_chunk) * ksteps;
+            const char *in_s = in_n + sl * (16 * nq);
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int j = wave + i * 4;
+                if (j < h_instr) glds16(hoff[i] != 0xFFFFFFFFu ? (const void *)(in_s + hoff[i]) : p.zero, buf + j * 1024);
+            }
+            char *wb = buf + (size_t)h_instr * 1024;
+            const char *wsrc = (const char *)p.wp + (size_t)q * chunk_bytes + s0 * 1024;
+#pragma unroll
+            for (int i = 0; i < MAXW; ++i) {
+                const int f = wave + 4 * i;
+                if (f < w_instr) glds16(wsrc + woff[i], wb + f * 1024);
+            }
+            for (int f = wave + 4 * MAXW; f < w_instr; f += 4) {  // (k = 5: more than 40 pieces)
+                const int tl = f / (NT * ksteps), rest = f - tl * (NT * ksteps);
+                const int nt = rest / ksteps, s = rest - nt * ksteps;
+                glds16(wsrc + ((p.wt[tl] * (NT * 2) + nt * 2 + s) * 1024) + lane * 16, wb + f * 1024);
+            }
+        };
+        issue(0, smem);
+        for (int sl = 0; sl < slices; ++sl) {
+            char *cur = smem + (size_t)(sl & 1) * buf_bytes;
+            wait_vm0();
+            __syncthreads();  // slice sl landed; the other buffer's readers (slice sl - 1) are done
+            if (sl + 1 < slices && !(GG_ABL & 2)) issue(sl + 1, smem + (size_t)((sl + 1) & 1) * buf_bytes);
+            const char *wcur = cur + (size_t)h_instr * 1024;
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int hr = arow + p.dy[t] - p.dymin, hc = acol + p.dx[t] - p.dxmin;
+                for (int s = 0; s < ksteps; ++s) {
+                    const char *ab = (GG_ABL & 4) ? cur + lane * 16 : cur + ((((2 * s + h) * p.HR + hr) * p.HC + hc) * 16);
+                    const bf16x8 a0 = *(const bf16x8 *)ab;
+                    const bf16x8 a1 = *(const bf16x8 *)(ab + 2 * p.S * p.HC * 16);  // m-tile 1: two rows down
+                    const char *wb = wcur + ((t * NT) * ksteps + s) * 1024 + lane * 16;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bf16x8 b = *(const bf16x8 *)(wb + nt * ksteps * 1024);
+                        if (GG_ABL & 1) {
+                            acc[0][nt][0] += (float)a0[0] * (float)b[0];
+                            acc[1][nt][0] += (float)a1[0] * (float)b[1];
+                        } else {
+                            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0][nt], 0, 0, 0);
+                            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1][nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
     const int chunks = p.Ck / 32;
     for (int q = 0; q < chunks; ++q) {
         __syncthreads();  // the previous chunk's reads of the halo are done
@@ -138,7 +216,7 @@ __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
         for (int i = 0; i < MAXP; ++i) {
             const int j = wave + i * 4;
             if (j < halo_instr) {
-                const void *src = hoff[i] >= 0 ? (const void *)(in_n + hoff[i] + q * 64) : p.zero;
+                const void *src = hoff[i] != 0xFFFFFFFFu ? (const void *)(in_n + hoff[i] + q * 64) : p.zero;
                 glds16(src, halo + j * 1024);
             }
         }
@@ -174,6 +252,8 @@ __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
         }
     }
 
+    }
+
     // D: lane = output channel 32nt + m, register r = position acc_row(r) + 4h of the m-tile
     static_for<2>([&](auto pt_tag) {
         constexpr int pt = decltype(pt_tag)::value;
@@ -182,7 +262,7 @@ __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
             const int mp = acc_row(r) + 4 * h;
             const int li = i0 + 4 * wave + 2 * pt + (mp >> 4), lj = j0 + (mp & 15);
             const int oy = p.SO * li + p.oy0, ox = p.SO * lj + p.ox0;
-            if (li < p.LH && lj < p.LW && oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
+            if (li < p.LH && lj < p.LW && oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW && (!(GG_ABL & 8) || p.N < 0)) {
                 const size_t base = (((size_t)n * p.OH + oy) * p.OW + ox) * p.Cn + m;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {

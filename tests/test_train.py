@@ -219,7 +219,13 @@ def test_track_gradients_match_the_restatement(cae, cfgkw, shape):
         for key, sub in (('weight', 'model.0.weight'), ('bias', 'model.0.bias'), ('beta', 'model.1.beta'), ('gamma', 'model.1.gamma')):
             if l.get(key) is not None:
                 name = f'analysis_track.{i}.{sub}'
-                assert rel(got[name], l[key].grad) < 1e-3, name
+                # The restatement rounds to bf16 at the kernels' rounding points, so the two sides differ by summation
+                # order only -- but an activation within float noise of a bf16 rounding boundary then rounds the other way
+                # (2^-9 of its value), and a layer whose gradient sums over a few positions only (here down to 4 x 4)
+                # shows single flips: measured 2.6e-4 .. 1.2e-3 on the last two layers for two summation orders of the
+                # same kernels (chunk-wise / slice-wise staging), 1e-6 .. 7e-5 on the first two.
+                positions = n * -(-h // 2 ** (i + 1)) * -(-w // 2 ** (i + 1))
+                assert rel(got[name], l[key].grad) < (1e-3 if positions >= 256 else 2.5e-3), name
     # synthesis (from latents of realistic magnitude; h, w even multiples are not required)
     lh, lw = y.shape[2:]
     yq = torch.round(y_ref.detach()).requires_grad_(True)
