@@ -129,7 +129,8 @@ static bool fits_f16(const float *v, size_t n) {
 }
 
 // weights -> [q][ky][kx][ct][hl][lane][8]: W(cout = 32ct + (lane&31), cin = 16q + 8(lane>>5) + j, ky, kx)
-static std::vector<_Float16> pack_weights_f16(const float *w, bool transposed, int cin, int cout, int ks, int ct) {
+static std::vector<_Float16> pack_weights_f16(const float *w, bool transposed, int cin, int cout, int ks, int ct,
+                                              bool flip = false) {
     const int nq = (cin + 15) / 16;
     std::vector<_Float16> out((size_t)nq * ks * ks * ct * 2 * 512, (_Float16)0.0f);
     for (int q = 0; q < nq; ++q)
@@ -141,9 +142,11 @@ static std::vector<_Float16> pack_weights_f16(const float *w, bool transposed, i
                             const int co = 32 * t + (lane & 31);
                             const int ci = 16 * q + 8 * (lane >> 5) + j;
                             float v = 0.0f;
-                            if (co < cout && ci < cin)
-                                v = transposed ? w[(((size_t)ci * cout + co) * ks + ky) * ks + kx]
-                                               : w[(((size_t)co * cin + ci) * ks + ky) * ks + kx];
+                            if (co < cout && ci < cin) {
+                                const int sy = flip ? ks - 1 - ky : ky, sx = flip ? ks - 1 - kx : kx;
+                                v = transposed ? w[(((size_t)ci * cout + co) * ks + sy) * ks + sx]
+                                               : w[(((size_t)co * cin + ci) * ks + sy) * ks + sx];
+                            }
                             _Float16 hi, lo;
                             split_half(v, hi, lo);
                             const size_t base = (((((size_t)q * ks + ky) * ks + kx) * ct + t) * 2) * 512;
@@ -333,9 +336,11 @@ bool Model::f16_usable() const {
 }
 
 static void free_stages(Layer &l) {
-    for (auto &sg : l.stages)
+    for (auto &sg : l.stages) {
+        if (sg.wp16) (void)hipFree(sg.wp16);
         for (float *q : {sg.wp, sg.bias, sg.gp, sg.beta})
             if (q) (void)hipFree(q);
+    }
     l.stages.clear();
 }
 
@@ -440,9 +445,16 @@ static int set_stage(Model *m, int track, Layer &l, int stage, const float *w, c
     sg.act = act;
     sg.add_res = add_residual != 0;
     sg.post_act = post_act;
-    if (l.wp_edge && track == CAE_ANALYSIS) {  // the fused first-layer kernel reads the raw tile; a stage sits in between
-        (void)hipFree(l.wp_edge);
+    if (m->precision == 1) {  // f16x3: the stage's weights as split halves (same packing as the strided layers)
+        if (!fits_f16(w, (size_t)l.cin * l.cin * m->ks * m->ks)) l.f16_bad = true;
+        auto w16 = pack_weights_f16(w, tr, l.cin, l.cin, m->ks, ctin, tr);
+        if ((rc = upload_raw(w16.data(), w16.size() * sizeof(_Float16), &sg.wp16))) return rc;
+    }
+    if (track == CAE_ANALYSIS) {  // the fused first-layer kernels read the raw tile; a stage sits in between
+        if (l.wp_edge) (void)hipFree(l.wp_edge);
+        if (l.wp_edge16) (void)hipFree(l.wp_edge16);
         l.wp_edge = nullptr;
+        l.wp_edge16 = nullptr;
     }
     return CAE_OK;
 }
@@ -457,7 +469,7 @@ static int pick_slot(int a, int b) {
 }
 
 static int run_stages(Model *m, const Layer &l, bool synthesis, int n, int ch, int cw, const float *&cur, int &cur_idx,
-                      int &cur_planes, hipStream_t st) {
+                      int &cur_planes, hipStream_t st, bool f16 = false, int *flag = nullptr) {
     const float *unit_in = cur;
     const int unit_idx = cur_idx, unit_planes = cur_planes;
     for (const Layer::Stage &sg : l.stages) {
@@ -488,7 +500,18 @@ static int run_stages(Model *m, const Layer &l, bool synthesis, int n, int ch, i
         b.res = sg.add_res ? unit_in : nullptr;
         b.res_planes = unit_planes;
         b.post_act = sg.post_act;
-        int rc = launch_conv_s1(m->ks, ctin, synthesis, sg.gdn, b, st);
+        int rc;
+        if (f16) {  // activation stage of a LeakyReLU / ReLU unit on the split-f16 kernels
+            if (sg.gdn || sg.add_res || sg.post_act || !sg.wp16)
+                return fail(CAE_ERR_UNSUPPORTED, "GDN / residual stride-1 stages run on the fp32 path: set precision 0");
+            b.wp = (const float *)sg.wp16;
+            b.cci = (l.cin + 15) / 16;
+            b.tiles_y = (ch + 15) / 16;
+            b.flag = flag;
+            rc = launch_conv_s1_f16(m->ks, ctin, synthesis, b, st);
+        } else {
+            rc = launch_conv_s1(m->ks, ctin, synthesis, sg.gdn, b, st);
+        }
         if (rc) return rc;
         cur = (const float *)b.out;
         cur_idx = out_idx;
@@ -638,8 +661,6 @@ int cae_model_set_layer_act(cae_model_t *mm, int track, int index, int act, cons
     Layer &l = (track == CAE_ANALYSIS ? m->enc : m->dec)[index];
     if (!l.set) return fail(CAE_ERR_ARG, "set the layer before its activation");
     if (l.gdn && (act != 0 || pre_w)) return fail(CAE_ERR_ARG, "a GDN unit has no other activation");
-    if ((act != 0 || pre_w) && m->precision != 0)
-        return fail(CAE_ERR_UNSUPPORTED, "LeakyReLU / ReLU units run on the fp32 path: set precision 0");
     if (pre_b && !pre_w) return fail(CAE_ERR_ARG, "pre-convolution bias without weight");
     l.act = act;
     free_stages(l);
@@ -789,7 +810,7 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
         int ch = h, cw = w;
         for (int i = 0; i < m->L; ++i) {
             if (!m->enc[i].stages.empty())  // stride-1 stages: same size, cin channels
-                maxact = std::max(maxact, (size_t)n * round_ct(m->enc[i].cin) * 4 * ch * cw * 32);
+                maxact = std::max(maxact, (size_t)n * round_ct(m->enc[i].cin) * 4 * ch * row_bytes(cw));
             ch = (ch + 1) / 2;
             cw = (cw + 1) / 2;
             if (i + 1 < m->L) maxact = std::max(maxact, (size_t)n * m->enc[i].ct * 4 * ch * row_bytes(cw));
@@ -835,7 +856,7 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
     for (int i = 0; i < m->L; ++i) {
         const Layer &l = m->enc[i];
         const bool last = i == m->L - 1;
-        if (!l.stages.empty() && (rc = run_stages(m, l, false, n, ch, cw, cur, cur_idx, cur_planes, st))) return rc;
+        if (!l.stages.empty() && (rc = run_stages(m, l, false, n, ch, cw, cur, cur_idx, cur_planes, st, f16, flag))) return rc;
         LayerArgs a{};
         a.in = cur;
         const int out_idx = pick_slot(cur_idx, cur_idx);
@@ -961,7 +982,7 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
         int ch = lh, cw = lw;
         for (int i = 0; i < m->L; ++i) {
             if (!m->dec[i].stages.empty())
-                maxact = std::max(maxact, (size_t)n * round_ct(m->dec[i].cin) * 4 * ch * cw * 32);
+                maxact = std::max(maxact, (size_t)n * round_ct(m->dec[i].cin) * 4 * ch * row_bytes(cw));
             ch *= 2;
             cw *= 2;
             if (i + 1 < m->L) maxact = std::max(maxact, (size_t)n * m->dec[i].ct * 4 * ch * row_bytes(cw));
@@ -1014,7 +1035,7 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
             prof.end();
             break;
         }
-        if (!l.stages.empty() && (rc = run_stages(m, l, true, n, ch, cw, cur, cur_idx, cur_planes, st))) return rc;
+        if (!l.stages.empty() && (rc = run_stages(m, l, true, n, ch, cw, cur, cur_idx, cur_planes, st, f16, flag))) return rc;
         LayerArgs a{};
         a.in = cur;
         const int out_idx = pick_slot(cur_idx, cur_idx);

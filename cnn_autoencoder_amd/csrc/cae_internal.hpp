@@ -25,6 +25,7 @@ struct Layer {
     // LeakyReLU / ReLU units and the res_model of the residual units (_autoencoders.py:62-76, :104-174, :230-304)
     struct Stage {
         float *wp = nullptr, *bias = nullptr, *gp = nullptr, *beta = nullptr;
+        void *wp16 = nullptr;  // f16x3 path: packed hi/lo weights (activation stages; GDN / residual stages are fp32 only)
         bool gdn = false;      // GDN (analysis) / IGDN (synthesis) after the convolution, else `act`
         int act = 0;
         bool add_res = false;  // + the unit's input after the activation (residual units)

@@ -267,10 +267,20 @@ __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const L
     // (the half-wave exchange of the split store needs both lanes of a pixel: lanes l and l+32 share (oy, ox),
     //  hence the same `valid`; invalid pairs skip the whole store)
     if (!valid) return;
-    if (p.outfmt == OUT_C8)
-        store_split_f16<CT, SP>(acc, p, n, oy, ox, h);
-    else
-        store_tiles<CT, false>(acc, p, n, oy, ox, h, valid);  // the f16x3 path has no activation variants
+    if (p.outfmt == OUT_C8) {
+        if (p.act) {  // LeakyReLU / ReLU units (_autoencoders.py:62-76, :187-202): the activation before the split store
+            f32x16 t[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[ct][r] = apply_act(acc[ct][r], p.act);
+            store_split_f16<CT, SP>(t, p, n, oy, ox, h);
+        } else {
+            store_split_f16<CT, SP>(acc, p, n, oy, ox, h);
+        }
+    } else {
+        store_tiles<CT, false>(acc, p, n, oy, ox, h, valid);  // (last layers: no activation)
+    }
 }
 
 // =================================================================================================
@@ -285,12 +295,16 @@ __device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const L
 #ifndef CAE_CONV_F16_NW
 #define CAE_CONV_F16_NW 8
 #endif
-template <int KS, int CT, bool GDN>
+// S = 1 (the stride-1 convolution in front of the strided one in LeakyReLU / ReLU units, _autoencoders.py:62-76): same
+// staging, WH = 16 + KS - 1 halo columns.  SP: rows in and out are C8SP (synthesis track); ZP: zero padding instead of
+// reflection -- the synthesis units' ConvTranspose2d(stride 1, padding k//2) (:187-202) is the zero-padded correlation
+// with the flipped kernel (flipped when packed).
+template <int KS, int CT, bool GDN, int S = 2, bool SP = false, bool ZP = false>
 __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(const LayerArgs p) {
     constexpr int NW = CAE_CONV_F16_NW, PT = 8 / NW;  // 8 waves x 1 column tile (shipped) | 4 waves x 2
     constexpr int PAD = KS / 2;
     constexpr int TX = 16, TY = 16;
-    constexpr int WH = 2 * TX + KS - 2;
+    constexpr int WH = S * TX + KS - S;
     // (Round 2 tried an "aligned" halo image -- the 32 columns that coincide with one 32-pixel group of the C8S rows as
     //  whole 512-byte runs, the KS - 2 stray columns apart: no gain (profiles/r02_experiments.md 4), and its 512-byte row
     //  pitch made the stride-2 operand reads 2-way bank conflicted (1.4 conflict cycles per LDS-active cycle); the
@@ -325,9 +339,9 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
     const int n = bid / p.tiles_y;
     const int oy0 = ty * TY, ox0 = tx * TX;
 
-    const size_t plane_bytes = (size_t)p.H * c8s_row_bytes<false>(p.W);
+    const size_t plane_bytes = (size_t)p.H * c8s_row_bytes<SP>(p.W);
     const char *in_n = (const char *)p.in + (size_t)n * p.in_planes * plane_bytes;
-    unsigned hoff[MAXP][KS];
+    unsigned hoff[MAXP][KS];  // ZP: 0xFFFFFFFF = outside the image (the zero page)
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         int pc = (ISSUER(wave, NW, NI) + i * NI) * 64 + lane;
@@ -335,12 +349,19 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
         const int plhl = pc / PLANE_PIECES;
         const int rem = pc - plhl * PLANE_PIECES;
         const int r = rem / WH, x = rem - r * WH;
+        const int xi = S * ox0 - PAD + x;
+        const bool xin = xi >= 0 && xi < p.W;
         const unsigned base = (unsigned)(plhl >> 1) * (unsigned)plane_bytes + (unsigned)(plhl & 1) * 512u +
-                              c8s_piece<false>(reflect_idx(2 * ox0 - PAD + x, p.W));
+                              c8s_piece<SP>(ZP ? (xin ? xi : 0) : reflect_idx(xi, p.W));
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky)
-            hoff[i][ky] = base + (unsigned)reflect_idx(2 * (oy0 + r) - PAD + ky, p.H) *
-                                     (unsigned)c8s_row_bytes<false>(p.W);
+        for (int ky = 0; ky < KS; ++ky) {
+            const int yi = S * (oy0 + r) - PAD + ky;
+            if (ZP)
+                hoff[i][ky] = (xin && yi >= 0 && yi < p.H) ? base + (unsigned)yi * (unsigned)c8s_row_bytes<SP>(p.W)
+                                                            : 0xFFFFFFFFu;
+            else
+                hoff[i][ky] = base + (unsigned)reflect_idx(yi, p.H) * (unsigned)c8s_row_bytes<SP>(p.W);
+        }
     }
     const unsigned woff = (unsigned)lane * 16u;
 
@@ -364,7 +385,10 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             const int j = iw + i * NI;
-            if (j < HALO_INSTR) glds16(planes + hoff[i][ky], buf + W_BYTES + j * 1024);
+            if (j < HALO_INSTR) {
+                const void *src = (ZP && hoff[i][ky] == 0xFFFFFFFFu) ? (const void *)p.zero : (const void *)(planes + hoff[i][ky]);
+                glds16(src, buf + W_BYTES + j * 1024);
+            }
         }
     };
 
@@ -372,8 +396,8 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) init_acc<CT>(acc[pt], p.bias, h, 0.0f);
 
-    // B operand of (column tile pt, tap kx): halo [pl = h][hl][row 4w + 2pt + (m>>4)][2(m&15) + kx]
-    const int b_off = W_BYTES + (((2 * h) * TY + 2 * PT * wave + (m >> 4)) * WH + 2 * (m & 15)) * 16;
+    // B operand of (column tile pt, tap kx): halo [pl = h][hl][row 4w + 2pt + (m>>4)][S (m&15) + kx]
+    const int b_off = W_BYTES + (((2 * h) * TY + 2 * PT * wave + (m >> 4)) * WH + S * (m & 15)) * 16;
     constexpr int B_HL = PLANE_PIECES * 16;  // hi -> lo
     constexpr int B_PT = 2 * WH * 16;        // column tile 0 -> 1 (two rows down)
     int sc = 0;
@@ -437,7 +461,7 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int oy = oy0 + 2 * PT * wave + 2 * pt + (m >> 4), ox = ox0 + (m & 15);
-        store_tiles_f16<CT>(acc[pt], p, n, oy, ox, h, oy < p.OH && ox < p.OW);
+        store_tiles_f16<CT, SP>(acc[pt], p, n, oy, ox, h, oy < p.OH && ox < p.OW);
     }
 }
 

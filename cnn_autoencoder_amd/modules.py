@@ -417,7 +417,8 @@ class _Track(nn.Module):
     def precision_code(self) -> int:
         """0 = exact fp32 MFMA, 1 = f16x3 split MFMA.  Attribute `precision` ('fp32' | 'f16x3'), else the
         CAE_PRECISION environment variable, else 'f16x3' (fp32-class accuracy at ~2x the throughput;
-        GDN layers wider than 128 channels run their normalisation as a separate f16x3 kernel)."""
+        GDN layers wider than 128 channels run their normalisation as a separate f16x3 kernel).  Residual units and
+        multiscale colour layers are built on the fp32 kernels only."""
         import os
         prec = getattr(self, 'precision', None) or os.environ.get('CAE_PRECISION', 'f16x3')
         if prec not in ('fp32', 'f16x3'):
@@ -426,8 +427,7 @@ class _Track(nn.Module):
             return 0  # residual units: stride-1 stages on the fp32 kernels
         if getattr(self, 'multiscale_analysis', False):
             return 0  # colour layers are stride-1 convolutions on the fp32 kernels
-        if any(u.act_code for u in self._units()):
-            return 0  # LeakyReLU / ReLU units (stride-1 pre-convolutions) are built on the fp32 kernels
+        # (LeakyReLU / ReLU units: the stride-1 pre-convolutions run on the split-f16 kernel too, conv_s2_f16_kernel<.., S = 1>)
         return 1 if prec == 'f16x3' else 0
 
     def _units(self):

@@ -71,7 +71,7 @@ int cae_model_set_layer(cae_model_t *m, int track, int index, int cin, int cout,
  * (transposed) convolution; when pre_weight_host is given, a stride-1 convolution cin -> cin (analysis:
  * weight (cin,cin,k,k), reflect padding; synthesis: ConvTranspose2d weight (cin,cin,k,k), padding k//2)
  * plus the same activation runs in front of it.  Call after cae_model_set_layer for the same index.
- * These variants run on the fp32 path. */
+ * Both arithmetic paths (f16x3: the same split-f16 kernels with stride 1 / the activation in the store epilogue). */
 int cae_model_set_layer_act(cae_model_t *m, int track, int index, int act, const float *pre_weight_host,
                             const float *pre_bias_host);
 

@@ -311,6 +311,30 @@ def test_full_size_properties(cae):
                                rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('name', ['lrelu_bias_small_40x56', 'relu_small_37x45', 'lrelu_k5_mid_48x48'])
+def test_activation_units_stay_on_the_selected_arithmetic(cae, name, precision):
+    """LeakyReLU / ReLU units (the reference's default act_layer_type; stride-1 pre-convolutions, _autoencoders.py:62-76,
+    :187-202) run on the split-f16 kernels when f16x3 is selected (round 2 sent them to the fp32 kernels silently): the
+    handle reports the arithmetic it uses, no fp32 repeat happens, and the codec round trip matches the oracle."""
+    import ctypes
+    from cnn_autoencoder_amd import _lib
+    g, cfg = load_golden(name)
+    state = golden_state(g, cfg)
+    model = build_model(cae, state)
+    enc, dec = model['encoder'].module, model['decoder'].module
+    want = 1 if precision == 'f16x3' else 0
+    assert enc.precision_code() == want and dec.precision_code() == want
+    x = torch.from_numpy(g['tile']).permute(2, 0, 1).unsqueeze(0).float() / 255.0
+    y = model['encoder'](x.cuda()).cpu()
+    np.testing.assert_allclose(y.numpy(), g['y'], rtol=RTOL, atol=ATOL)
+    x_r, _ = model['decoder'](torch.round(torch.from_numpy(g['y'])).cuda())
+    np.testing.assert_allclose(x_r[0].cpu().numpy(), g['x_r'], rtol=RTOL, atol=ATOL)
+    for track in (enc, dec):
+        eff = ctypes.c_int(-1)
+        _lib.check(_lib.lib().cae_model_effective_precision(track._sync().ptr, ctypes.byref(eff)))
+        assert eff.value == want and track.fp32_fallbacks == 0
+
+
 @pytest.mark.parametrize('kind', ['histo', 'uniform'])
 def test_full_size_tile_against_the_oracle(cae, kind, precision):
     """BASELINE's tile size (canonical 128/192/L4 model, one 1024x1024x3 tile of each synthetic kind), both arithmetic
