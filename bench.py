@@ -27,6 +27,7 @@ Objects in the line besides the driver's contract:
   cpu_baseline  the CPU oracle (torch-CPU conv + restated GDN + C rANS) on a bounded sample of the
                 same tiles on this host's cores -- a reported baseline, not the target
   parity_vs_cpu the GPU path against that oracle on the very same tiles: bpp, PSNR, bitstreams, pixels
+  low_rate_state (N=1) the same workload with a low-rate synthetic state (~0.9 bpp instead of 4): brackets the host coder's cost
   train         (N=1) BASELINE config 5: train.train_step on 256x256 patches, batch 16 and 128, against the mixed
                 bf16-conv / fp32-GDN roofline
   dropin        (N=1) the reference's OWN call pattern: 1 / 8 / 16 Python threads calling codec.encode(chunk) /
@@ -263,9 +264,12 @@ def make_coder(cae, slide, state, precision):
     return slide.SlideCoder(codec)
 
 
-def sub_run(cae, slide, cfg, state, precision, H, tiles_dev, steps, warmup, dist):
+def sub_run(cae, slide, cfg, state, precision, H, tiles_dev, steps, warmup, dist, fit=False):
     """A short N=1 run of another configuration, reported next to the headline: tiles/s, ms/step, dominant kernel."""
     coder = make_coder(cae, slide, state, precision)
+    if fit:
+        coder.eb.fit_quantiles()
+        coder.eb.update(force=True)
     B = tiles_dev.shape[0]
     batches = batch_variants(tiles_dev, 4)
     dt, stats, prof = profiled_run(coder, batches, steps, warmup, 1, dist, tiles_dev.device)
@@ -273,9 +277,11 @@ def sub_run(cae, slide, cfg, state, precision, H, tiles_dev, steps, warmup, dist
     dom = max(kernels, key=lambda k: k['ms'])
     summ = slide.slide_summary(stats, H * H)
     fallbacks = coder.enc.fp32_fallbacks + coder.dec.fp32_fallbacks
+    host_ms = {k: 1e3 * v / steps for k, v in coder.timers.items()}
     del coder
     torch.cuda.empty_cache()
     return dict(precision=precision, tile=H, tiles_per_step=B, steps=steps, tiles_per_s=steps * B / dt,
+                host_ms_per_step=host_ms, host_cpus_busy=HOST_USE.get('cpus_busy'),
                 ms_per_step=1e3 * dt / steps, bpp=summ['bpp'], psnr_db=summ['psnr'],
                 dominant_kernel=dict(name=dom['name'], ms=dom['ms'], issued_tflops=dom['issued_tflops'],
                                      peak=peak, frac=dom['frac_of_issued_peak'],
@@ -416,9 +422,11 @@ def main():
         gpu_ms = (sum(prof[0]) / max(prof[1], 1), sum(prof[2]) / max(prof[3], 1))
         f16 = args.precision == 'f16x3'
         from cnn_autoencoder_amd import _lib
-        threads = dict(encode=int(_lib.lib().cae_coder_threads(coder.encode_threads, (B + 1) // 2)),
-                       decode=int(_lib.lib().cae_coder_threads(coder.decode_threads, (B + 1) // 2)),
-                       cpu_budget=int(_lib.lib().cae_cpu_budget()))
+        lock = int(_lib.lib().cae_coder_lockstep())
+        threads = dict(encode=int(_lib.lib().cae_coder_threads(coder.encode_threads, (B + lock - 1) // lock)),
+                       decode=int(_lib.lib().cae_coder_threads(coder.decode_threads, (B + lock - 1) // lock)),
+                       cpu_budget=int(_lib.lib().cae_cpu_budget()), lockstep=lock,
+                       cpus_allowed=len(os.sched_getaffinity(0)))
         line = {
             'metric': 'tiles/sec, compress+decompress round trip of 1024x1024x3 histology tiles',
             'value': total_tiles / dt,
@@ -509,6 +517,10 @@ def main():
             line['tile256'] = sub_run(cae, slide, cfg, state, args.precision, 256, t256, 16, 2, dist)
             del t256
             torch.cuda.empty_cache()
+            # the other end of what the host range coder sees: a low-rate state (most symbols zero under a narrow prior,
+            # standing in for a trained model) on the same tiles
+            low = synth.synthetic_state(cfg, seed=0, **synth.LOW_RATE)
+            line['low_rate_state'] = sub_run(cae, slide, cfg, low, args.precision, H, tiles_dev, 16, 2, dist, fit=True)
             # BASELINE config 5 (train_cae_ms.py rate-distortion loop): canonical model, 256x256 patches
             line['train'] = {
                 'dtype': 'bf16 convolutions (fp32 accumulate), fp32 GDN / IGDN (v_mfma_f32_32x32x2_f32), fp32 optimiser',

@@ -95,6 +95,7 @@ SYMBOLS = {
     'cae_t_density_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float,
                                        c_void_p, c_void_p, c_void_p]),
     'cae_cpu_budget': (c_int, []),
+    'cae_coder_lockstep': (c_int, []),
     'cae_coder_threads': (c_int, [c_int, c_int]),
     'cae_pmf_to_quantized_cdf': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'cae_rans_encode_batch': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),

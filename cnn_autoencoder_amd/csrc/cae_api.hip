@@ -1074,6 +1074,9 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
                 a.tiles_y = (ch + 3) / 4;
                 if ((rc = launch_last_f16(m->ks, a, st))) return rc;
             } else {
+                if (l.act && l.ct > 4)  // (the 192-channel transposed-convolution kernel carries no activation: registers)
+                    return fail(CAE_ERR_UNSUPPORTED, "f16x3: LeakyReLU / ReLU synthesis layers wider than 128 channels run "
+                                                     "on the fp32 path: set precision 0");
                 a.wp = (const float *)l.wp16;
                 a.cci = (l.cin + 15) / 16;
                 a.tiles_y = (ch + 7) / 8;

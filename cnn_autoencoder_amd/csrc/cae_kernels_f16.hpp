@@ -261,23 +261,24 @@ __device__ __forceinline__ void store_split_f16(const f32x16 (&acc)[CT], const L
     }
 }
 
-template <int CT, bool SP = false>
-__device__ __forceinline__ void store_tiles_f16(const f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
+template <int CT, bool SP = false, bool MAY_ACT = false>
+__device__ __forceinline__ void store_tiles_f16(f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
                                                 int h, bool valid) {
     // (the half-wave exchange of the split store needs both lanes of a pixel: lanes l and l+32 share (oy, ox),
     //  hence the same `valid`; invalid pairs skip the whole store)
     if (!valid) return;
     if (p.outfmt == OUT_C8) {
-        if (p.act) {  // LeakyReLU / ReLU units (_autoencoders.py:62-76, :187-202): the activation before the split store
-            f32x16 t[CT];
+        if constexpr (MAY_ACT) {
+            // LeakyReLU / ReLU units (_autoencoders.py:62-76, :187-202): the activation before the split store, in place and
+            // branch-free (slope 1 = no activation; a branch on p.act around the tile made the 192-channel kernels spill).
+            // Only the kernels without a fused GDN carry it: GDN units have no other activation.
+            const float slope = p.act == 0 ? 1.0f : (p.act == 1 ? 0.01f : 0.0f);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) t[ct][r] = apply_act(acc[ct][r], p.act);
-            store_split_f16<CT, SP>(t, p, n, oy, ox, h);
-        } else {
-            store_split_f16<CT, SP>(acc, p, n, oy, ox, h);
+                for (int r = 0; r < 16; ++r) acc[ct][r] = acc[ct][r] > 0.0f ? acc[ct][r] : slope * acc[ct][r];
         }
+        store_split_f16<CT, SP>(acc, p, n, oy, ox, h);
     } else {
         store_tiles<CT, false>(acc, p, n, oy, ox, h, valid);  // (last layers: no activation)
     }
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int oy = oy0 + 2 * PT * wave + 2 * pt + (m >> 4), ox = ox0 + (m & 15);
-        store_tiles_f16<CT, SP>(acc[pt], p, n, oy, ox, h, oy < p.OH && ox < p.OW);
+        store_tiles_f16<CT, SP, !GDN>(acc[pt], p, n, oy, ox, h, oy < p.OH && ox < p.OW);
     }
 }
 
@@ -878,7 +879,7 @@ __global__ void __launch_bounds__(512, 1) conv_first_f16_kernel(const LayerArgs 
         if constexpr (GDN) gdn_resident_f16<CT, false>(acc, gbuf, beta_lds, lane);
 #endif
         const int oy = ty * TY + 2 * wave + (m >> 4), ox = tx * TX + (m & 15);
-        store_tiles_f16<CT>(acc, p, n, oy, ox, h, oy < p.OH && ox < p.OW);
+        store_tiles_f16<CT, false, !GDN>(acc, p, n, oy, ox, h, oy < p.OH && ox < p.OW);
     }
 }
 
@@ -1264,7 +1265,7 @@ __device__ __forceinline__ void deconv_phase_f16(const LayerArgs &p, const char 
         if (p.outfmt == OUT_PMAP)
             store_pmap_f16<CT>(acc[x][pt], p, tbuf, n, 2 * (iy + pt) + PY, x, ix - (lane & 31), lane, (iy + pt) < p.H);
         else
-            store_tiles_f16<CT, true>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h, (iy + pt) < p.H && ix < p.W);
+            store_tiles_f16<CT, true, !IGDN && CT <= 4>(acc[x][pt], p, n, 2 * (iy + pt) + PY, 2 * ix + x, h, (iy + pt) < p.H && ix < p.W);
     };
     if constexpr (IGDN && G::RESIDENT) {
         // gamma resident: no staging, no barriers; one (px, row tile) at a time (64 norm accumulators live)

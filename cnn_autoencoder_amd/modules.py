@@ -427,7 +427,10 @@ class _Track(nn.Module):
             return 0  # residual units: stride-1 stages on the fp32 kernels
         if getattr(self, 'multiscale_analysis', False):
             return 0  # colour layers are stride-1 convolutions on the fp32 kernels
-        # (LeakyReLU / ReLU units: the stride-1 pre-convolutions run on the split-f16 kernel too, conv_s2_f16_kernel<.., S = 1>)
+        # (LeakyReLU / ReLU units: the stride-1 pre-convolutions run on the split-f16 kernel too, conv_s2_f16_kernel<.., S = 1>;
+        #  the 192-channel transposed-convolution kernel carries no activation epilogue -- it would spill)
+        if self._track_id == _lib.CAE_SYNTHESIS and any(u.act_code and u.main.out_channels > 128 for u in self._units()):
+            return 0
         return 1 if prec == 'f16x3' else 0
 
     def _units(self):

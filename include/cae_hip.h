@@ -323,6 +323,9 @@ int cae_t_reparam_backward(const float *x, const float *g, long n, float bound, 
  * of a symbol is its channel c. */
 /* CPUs this process may keep busy: affinity mask, capped by the cgroup CPU quota, divided by LOCAL_WORLD_SIZE. */
 int cae_cpu_budget(void);
+/* Streams one coder thread walks in lockstep (2 or 4 independent chains per loop iteration; CAE_CODER_LOCKSTEP, else 4
+ * when fewer than 16 CPUs are available to this process: fewer CPU-seconds per symbol, half as many work items). */
+int cae_coder_lockstep(void);
 /* Size of the coder pool a cae_rans_*_batch call with `threads` = requested and n_streams streams uses. */
 int cae_coder_threads(int requested, int n_streams);
 

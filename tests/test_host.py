@@ -199,7 +199,8 @@ def test_hot_kernels_keep_their_accumulators_in_registers(cae):
     table = sc.kernel_table(cae.LIB_PATH)
     names = list(table)
     nice = dict(zip(sc.demangle(names), names))
-    hot = ['conv_s2_f16_kernel<3, 4, true>', 'conv_s2_f16_kernel<3, 6, false>', 'conv_s2_f16_kernel<5, 4, true>',
+    hot = ['conv_s2_f16_kernel<3, 4, true, 2,', 'conv_s2_f16_kernel<3, 6, false, 2,', 'conv_s2_f16_kernel<5, 4, true, 2,',
+           'conv_s2_f16_kernel<3, 4, false, 1,',
            'deconv_s2_f16_kernel<3, 4, 8, 1, true>', 'deconv_s2_f16_kernel<3, 4, 8, 1, false>',
            'deconv_last_f16_kernel<3, 8, 3>', 'conv_s2_kernel<3, 4, 4, true, 2, false, false>',
            'conv_s2_kernel<3, 6, 4, false, 2, false, false>', 'deconv_last_kernel<3', 'likelihood_kernel<3>']
@@ -237,7 +238,8 @@ def test_unsupported_variants_say_so(cae):
     a = cae.Analyzer(3, 8, 16, 3, act_layer_type='LeakyReLU', bias=True)
     assert list(a.state_dict()) == [f'analysis_track.{i}.model.{j}.{p}' for i, js in ((0, (0, 2)), (1, (0, 2)), (2, (0,)))
                                     for j in js for p in ('weight', 'bias')]
-    assert a.precision_code() == 0  # these variants run on the fp32 kernels
+    assert a.precision_code() == 1  # (round 3: on the split-f16 kernels like the GDN model; residual units are not)
+    assert cae.Synthesizer(3, 160, 16, 3, act_layer_type='ReLU').precision_code() == 0  # > 128 channels with an activation
     assert cae.Synthesizer(3, 8, 16, 3, multiscale_analysis=True).precision_code() == 0  # colour layers: fp32 kernels
     with pytest.raises(NotImplementedError, match='training mode'):  # BatchNorm folds in eval mode only
         cae.Analyzer(3, 8, 16, 3, batch_norm=True).train().analysis_track[0].effective_main()
