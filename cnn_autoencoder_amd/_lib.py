@@ -109,6 +109,7 @@ SYMBOLS = {
                                       ctypes.POINTER(c_int)]),
     'cae_door_decode': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
     'cae_door_stats': (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    'cae_door_hold': (c_int, [c_void_p, c_int]),
 }
 
 CAE_ANALYSIS, CAE_SYNTHESIS = 0, 1

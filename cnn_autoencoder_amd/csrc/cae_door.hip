@@ -126,7 +126,7 @@ struct cae_door {
     std::deque<Request *> q;
     std::deque<Flight *> cq;
     std::vector<std::unique_ptr<Flight>> flights;
-    bool stop = false, dispatcher_gone = false;
+    bool stop = false, dispatcher_gone = false, hold = false;
     std::thread dispatcher, completer;
     PinnedPool staging{64}, results{8};
     // statistics (seconds summed over chunks; guarded by stat_mu)
@@ -264,7 +264,7 @@ void cae_door::dispatch_loop() {
         Flight *f = nullptr;
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv_work.wait(lk, [&] { return stop || !q.empty(); });
+            cv_work.wait(lk, [&] { return stop || (!q.empty() && !hold); });
             if (q.empty()) break;  // stop, nothing pending
             // requests keep piling up while every flight is on the device
             cv_flight.wait(lk, [&] {
@@ -513,9 +513,25 @@ int cae_door_decode(cae_door_t *door, const uint8_t *chunk, size_t len, uint8_t 
     return rc;
 }
 
+int cae_door_hold(cae_door_t *door, int on) {
+    if (!door) return fail(CAE_ERR_ARG, "NULL argument");
+    {
+        std::lock_guard<std::mutex> lk(door->mu);
+        door->hold = on != 0;
+    }
+    door->cv_work.notify_all();
+    return CAE_OK;
+}
+
 int cae_door_stats(cae_door_t *door, double *stats, int n, int reset) {
     if (!door || !stats || n < 0) return fail(CAE_ERR_ARG, "NULL argument");
+    size_t queued;
+    {
+        std::lock_guard<std::mutex> lk(door->mu);
+        queued = door->q.size();
+    }
     std::lock_guard<std::mutex> lk(door->stat_mu);
+    door->st[CAE_DOOR_STAT_QUEUED] = (double)queued;
     for (int i = 0; i < n; ++i) stats[i] = i < CAE_DOOR_STATS ? door->st[i] : 0.0;
     if (reset)
         for (double &v : door->st) v = 0.0;

@@ -26,7 +26,7 @@ import numpy as np
 from . import _lib
 
 _STAT_NAMES = ('batches', 'chunks', 'fp32_repeats', 'stage', 'wait', 'code', 'w_queue', 'w_launch', 'w_device', 'w_pull',
-               'w_wake')
+               'w_wake', 'queued')
 
 
 class FrontDoor:
@@ -76,6 +76,11 @@ class FrontDoor:
         buf = (ctypes.c_double * len(_STAT_NAMES))()
         _lib.check(_lib.lib().cae_door_stats(self._door, buf, len(_STAT_NAMES), int(reset)))
         return dict(zip(_STAT_NAMES, buf))
+
+    def hold(self, on: bool = True):
+        """While held the dispatcher starts no batch: calls queue up (``stats()['queued']``) and go out together --
+        ``max_batch`` at a time -- on ``hold(False)``."""
+        _lib.check(_lib.lib().cae_door_hold(self._door, int(bool(on))))
 
     @property
     def batches(self) -> int:

@@ -371,13 +371,16 @@ int cae_door_decode(cae_door_t *door, const uint8_t *chunk_host, size_t len, uin
 /* Counters since creation / the last reset: batches launched, chunks served, batches repeated on the fp32 kernels,
  * then seconds summed over the calls: caller staging (copy into pinned memory / range decode), caller waiting, caller
  * coding (range encode / copy out), and the waiting time split into queue, launch, device, pull (DMA to the host) and
- * wake-up. */
+ * wake-up; last: the calls waiting in the queue right now. */
 enum cae_door_stat {
     CAE_DOOR_STAT_BATCHES = 0, CAE_DOOR_STAT_CHUNKS, CAE_DOOR_STAT_FP32_REPEATS, CAE_DOOR_STAT_T_STAGE,
     CAE_DOOR_STAT_T_WAIT, CAE_DOOR_STAT_T_CODE, CAE_DOOR_STAT_T_QUEUE, CAE_DOOR_STAT_T_LAUNCH, CAE_DOOR_STAT_T_DEVICE,
-    CAE_DOOR_STAT_T_PULL, CAE_DOOR_STAT_T_WAKE, CAE_DOOR_STATS
+    CAE_DOOR_STAT_T_PULL, CAE_DOOR_STAT_T_WAKE, CAE_DOOR_STAT_QUEUED, CAE_DOOR_STATS
 };
 int cae_door_stats(cae_door_t *door, double *stats /* n */, int n, int reset);
+/* on != 0: the dispatcher starts no further batch (calls queue up; CAE_DOOR_STAT_QUEUED = the number waiting); 0: it
+ * resumes.  Lets a caller -- and the tests -- form batches deterministically. */
+int cae_door_hold(cae_door_t *door, int on);
 
 #ifdef __cplusplus
 }
