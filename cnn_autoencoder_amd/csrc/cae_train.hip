@@ -97,7 +97,7 @@ int launch_gg(GGArgs &a, hipStream_t st) {
 
 // strided correlation: position (i, j) <- input (2i + ky - P, 2j + kx - P), every tap
 int strided_corr(const void *in16, int n, int ih, int iw, int ck, const void *packed, int ks, int reflect, float *out32,
-                 void *out16, int cn, int oh, int ow, const float *bias, hipStream_t st) {
+                 void *out16, int cn, int oh, int ow, const float *bias, hipStream_t st, int act = 0) {
     if (ks != 3 && ks != 5) return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
     GGArgs a{};
     a.in = in16;
@@ -117,6 +117,7 @@ int strided_corr(const void *in16, int n, int ih, int iw, int ck, const void *pa
     a.S = 2;
     a.SO = 1;
     a.reflect = reflect;
+    a.act = act;
     a.ktaps = ks * ks;
     a.ntaps = ks * ks;
     const int P = ks / 2;
@@ -135,7 +136,7 @@ int strided_corr(const void *in16, int n, int ih, int iw, int ck, const void *pa
 //   shift = 0 : extended domain  out[Y] = sum in[(Y - ky) / 2],  Y in [0, 2 ih + k - 2]   (data gradient of a valid
 //               convolution on the reflect-padded input; Y = y + P)
 int strided_corr_t(const void *in16, int n, int ih, int iw, int ck, const void *packed, int ks, int shift, float *out32,
-                   void *out16, int cn, int oh, int ow, const float *bias, hipStream_t st) {
+                   void *out16, int cn, int oh, int ow, const float *bias, hipStream_t st, int act = 0) {
     if (ks != 3 && ks != 5) return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
@@ -160,6 +161,7 @@ int strided_corr_t(const void *in16, int n, int ih, int iw, int ck, const void *
             a.oy0 = py;
             a.ox0 = px;
             a.reflect = 0;
+            a.act = act;
             a.ktaps = ks * ks;
             int nt = 0;
             for (int ky = 0; ky < ks; ++ky) {
@@ -178,6 +180,47 @@ int strided_corr_t(const void *in16, int n, int ih, int iw, int ck, const void *
             if (rc) return rc;
         }
     return CAE_OK;
+}
+
+// stride-1 correlations of the LeakyReLU / ReLU units' pre-convolutions: position (i, j) <- input (i + d_ky, j + d_kx)
+//   mode 0  analysis pre-convolution forward      d = k - P, reflect padding                 (Conv2d(cin, cin, k, 1, k//2, reflect))
+//   mode 1  its data gradient, EXTENDED domain    position Y = y + P <- g[Y - k], zeros      (folded by the consumer)
+//   mode 2  synthesis pre-convolution forward     d = P - k, zeros                           (ConvTranspose2d(cin, cin, k, 1, k//2))
+//   mode 3  its data gradient                     d = k - P, zeros
+int stride1_corr(const void *in16, int n, int ih, int iw, int ck, const void *packed, int ks, int mode, float *out32,
+                 void *out16, int cn, const float *bias, int act, hipStream_t st) {
+    if (ks != 3 && ks != 5) return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+    if (mode < 0 || mode > 3) return fail(CAE_ERR_ARG, "bad mode %d", mode);
+    const int P = ks / 2;
+    GGArgs a{};
+    a.in = in16;
+    a.out32 = out32;
+    a.out16 = out16;
+    a.wp = packed;
+    a.bias = bias;
+    a.N = n;
+    a.IH = ih;
+    a.IW = iw;
+    a.Ck = ck;
+    a.Cn = cn;
+    a.OH = mode == 1 ? ih + 2 * P : ih;
+    a.OW = mode == 1 ? iw + 2 * P : iw;
+    a.LH = a.OH;
+    a.LW = a.OW;
+    a.S = 1;
+    a.SO = 1;
+    a.reflect = mode == 0;
+    a.act = act;
+    a.ktaps = ks * ks;
+    a.ntaps = ks * ks;
+    for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx) {
+            const int t = ky * ks + kx;
+            a.dy[t] = (short)(mode == 1 ? -ky : (mode == 2 ? P - ky : ky - P));
+            a.dx[t] = (short)(mode == 1 ? -kx : (mode == 2 ? P - kx : kx - P));
+            a.wt[t] = (short)t;
+        }
+    return launch_gg(a, st);
 }
 
 template <int NB>
@@ -312,6 +355,45 @@ int cae_t_conv_forward(const void *x16, int n, int h, int w, int cin_p, const vo
                         (hipStream_t)stream);
 }
 
+int cae_t_conv_forward_act(const void *x16, int n, int h, int w, int cin_p, const void *packed, int ks, float *z32, void *z16,
+                           int cout_p, const float *bias, int act, void *stream) {
+    if (!x16 || !packed || (!z32 && !z16)) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 2 || w < 2 || act < 0 || act > 2) return fail(CAE_ERR_ARG, "bad shape or activation");
+    return strided_corr(x16, n, h, w, cin_p, packed, ks, 1, z32, z16, cout_p, (h + 1) / 2, (w + 1) / 2, bias,
+                        (hipStream_t)stream, act);
+}
+
+int cae_t_deconv_forward_act(const void *x16, int n, int h, int w, int cin_p, const void *packed, int ks, float *z32, void *z16,
+                             int cout_p, const float *bias, int act, void *stream) {
+    if (!x16 || !packed || (!z32 && !z16)) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 1 || w < 1 || act < 0 || act > 2) return fail(CAE_ERR_ARG, "bad shape or activation");
+    return strided_corr_t(x16, n, h, w, cin_p, packed, ks, ks / 2, z32, z16, cout_p, 2 * h, 2 * w, bias, (hipStream_t)stream,
+                          act);
+}
+
+int cae_t_corr_s1(const void *x16, int n, int h, int w, int ck, const void *packed, int ks, int mode, float *out32, void *out16,
+                  int cn, const float *bias, int act, void *stream) {
+    if (!x16 || !packed || (!out32 && !out16)) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 1 || w < 1 || act < 0 || act > 2) return fail(CAE_ERR_ARG, "bad shape or activation");
+    return stride1_corr(x16, n, h, w, ck, packed, ks, mode, out32, out16, cn, bias, act, (hipStream_t)stream);
+}
+
+int cae_t_act_backward(const void *g16, float *gext32, int pad, const void *y16, int n, int h, int w, int cp, int act,
+                       void *out16, void *stream) {
+    if ((!g16 && !gext32) || !y16 || !out16) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 1 || w < 1 || pad < 0 || cp % 32 || act < 1 || act > 2) return fail(CAE_ERR_ARG, "bad shape or activation");
+    hipStream_t st = (hipStream_t)stream;
+    if (!g16 && pad > 0) {  // reflect fold of the extended-domain gradient, in place
+        hipLaunchKernelGGL(fold_inplace_kernel, dim3((unsigned)(n * h)), dim3(256), 0, st, gext32, h, w, pad, cp);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid((size_t)n * h * w * cp)), dim3(256), 0, st, (const __bf16 *)g16,
+                       FoldSrc{gext32, h, w, g16 ? 0 : pad}, (const __bf16 *)y16, act == 1 ? 0.01f : 0.0f, (__bf16 *)out16, n, h,
+                       w, cp);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
 int cae_t_conv_dgrad_ext(const void *gz16, int n, int oh, int ow, int cout_p, const void *packed, int ks, int h, int w,
                          float *gext32, int cin_p, void *stream) {
     if (!gz16 || !packed || !gext32) return fail(CAE_ERR_ARG, "NULL argument");
@@ -336,14 +418,29 @@ int cae_t_deconv_dgrad(const void *gz16, int n, int h, int w, int cout_p, const 
     return strided_corr(gz16, n, 2 * h, 2 * w, cout_p, packed, ks, 0, gx32, gx16, cin_p, h, w, nullptr, (hipStream_t)stream);
 }
 
+static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const void *ysmall16, int oh, int ow, int cb, int ks,
+                      int reflect, int S, float *gw32, void *stream);
+
 int cae_t_wgrad(const void *xbig16, int n, int h, int w, int ca, const void *ysmall16, int oh, int ow, int cb, int ks,
                 int reflect, float *gw32, void *stream) {
+    if (n < 1 || oh < 1 || ow < 1 || 2 * oh < h || 2 * ow < w) return fail(CAE_ERR_ARG, "bad shape");
+    return wgrad_impl(xbig16, n, h, w, ca, ysmall16, oh, ow, cb, ks, reflect, 2, gw32, stream);
+}
+
+int cae_t_wgrad_s1(const void *x16, int n, int h, int w, int ca, const void *y16, int cb, int ks, int reflect, float *gw32,
+                   void *stream) {
+    if (n < 1 || h < 1 || w < 1) return fail(CAE_ERR_ARG, "bad shape");
+    return wgrad_impl(x16, n, h, w, ca, y16, h, w, cb, ks, reflect, 1, gw32, stream);
+}
+
+static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const void *ysmall16, int oh, int ow, int cb, int ks,
+                      int reflect, int S, float *gw32, void *stream) {
     if (!xbig16 || !ysmall16 || !gw32) return fail(CAE_ERR_ARG, "NULL argument");
     if (ks != 3 && ks != 5) return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
     if (bad_channels(ca) || bad_channels(cb)) return fail(CAE_ERR_ARG, "channel counts must be multiples of 32, at most 192");
-    if (n < 1 || oh < 1 || ow < 1 || 2 * oh < h || 2 * ow < w) return fail(CAE_ERR_ARG, "bad shape");
     hipStream_t st = (hipStream_t)stream;
     WGArgs a{};
+    a.S = S;
     a.x = xbig16;
     a.y = ysmall16;
     a.gw = gw32;
@@ -366,8 +463,8 @@ int cae_t_wgrad(const void *xbig16, int n, int h, int w, int ca, const void *ysm
         }
     a.dymin = -P;
     a.dxmin = -P;
-    a.HR = 2 * 7 + ks;
-    a.HC = 2 * 15 + ks;
+    a.HR = S * 7 + ks;
+    a.HC = S * 15 + ks;
     a.tiles_x = (ow + 15) / 16;
     a.tiles_y = (oh + 7) / 8;
     a.total_tiles = n * a.tiles_x * a.tiles_y;

@@ -74,6 +74,7 @@ struct GGArgs {
     int S;              // input pixel of position (i, j) and tap t: (S i + dy[t], S j + dx[t])
     int SO, oy0, ox0;   // output pixel of position (i, j): (SO i + oy0, SO j + ox0)
     int reflect;        // 1: reflect padding of the input, 0: zeros outside
+    int act;            // activation on the way out: 0 none, 1 LeakyReLU(0.01), 2 ReLU (_autoencoders.py:19-34)
     int ntaps, ktaps;   // taps of this launch, taps of the packed weights (KS * KS)
     int dymin, dxmin, HR, HC;
     int taps_per_stage;
@@ -266,7 +267,8 @@ __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
                 const size_t base = (((size_t)n * p.OH + oy) * p.OW + ox) * p.Cn + m;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const float v = acc[pt][nt][r];
+                    float v = acc[pt][nt][r];
+                    if (p.act) v = v > 0.0f ? v : (p.act == 1 ? 0.01f * v : 0.0f);
                     if (p.out32) p.out32[base + 32 * nt] = v;
                     if (p.out16) ((__bf16 *)p.out16)[base + 32 * nt] = (__bf16)v;
                 }
@@ -288,6 +290,7 @@ struct WGArgs {
     const void *zero;
     int N, H, W, Ca, OH, OW, Cb;
     int reflect;       // padding of X: 1 reflect, 0 zeros
+    int S;             // X is sampled at S * position + tap offset: 2 (the strided layers) or 1 (the stride-1 pre-convolutions)
     int kk;            // taps of the layer
     int dymin, dxmin, HR, HC;
     int tiles_x, tiles_y, total_tiles;
@@ -338,7 +341,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WGArgs p) {
             pc = pc < x_pieces ? pc : x_pieces - 1;
             const int pix = pc >> 2, quarter = pc & 3;
             const int r = pix / p.HC, c = pix - r * p.HC;
-            int iy = 2 * i0 + p.dymin + r, ix = 2 * j0 + p.dxmin + c;
+            int iy = p.S * i0 + p.dymin + r, ix = p.S * j0 + p.dxmin + c;
             bool ok = true;
             if (p.reflect) {
                 iy = reflect_idx(iy, p.H);
@@ -382,13 +385,13 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WGArgs p) {
             static_for<9>([&](auto t_tag) {
                 constexpr int t = decltype(t_tag)::value;
                 if (t < ntaps) {
-                    const int hr = 2 * ks + p.dy[tap0 + t] - p.dymin;
+                    const int hr = p.S * ks + p.dy[tap0 + t] - p.dymin;
                     const int hc = p.dx[tap0 + t] - p.dxmin;
                     const char *xb = xbuf + (size_t)(hr * p.HC + hc) * 64 + col_off;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4 *)(xb + 2 * lj0 * 64));
+                        (__attribute__((address_space(3))) s16x4 *)(xb + p.S * lj0 * 64));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4 *)(xb + 2 * lj1 * 64));
+                        (__attribute__((address_space(3))) s16x4 *)(xb + p.S * lj1 * 64));
                     const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     const bf16x8 a = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
@@ -443,6 +446,30 @@ __device__ __forceinline__ float fold_read(const FoldSrc &f, int n, int y, int x
         for (int b = 0; b < nx; ++b)
             s += f.g[(((size_t)n * HP + ys[a] + f.P) * WP + xs[b] + f.P) * C + c];
     return s;
+}
+
+// Activation backward: out = g * (y > 0 ? 1 : slope), y = the activation's OUTPUT (LeakyReLU keeps the sign, ReLU's
+// output is positive exactly where its input was).  g: bf16 [N][H][W][C], or fp32 on the extended domain f (already
+// folded in place: fold_inplace_kernel), of which the interior is read.
+static __global__ void act_bwd_kernel(const __bf16 *g16, FoldSrc f, const __bf16 *y, float slope, __bf16 *out, int N, int H,
+                                      int W, int C) {
+    const size_t total = (size_t)N * H * W * C;
+    const int HP = H + 2 * f.P, WP = W + 2 * f.P;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float g;
+        if (g16) {
+            g = (float)g16[i];
+        } else {
+            const int c = (int)(i % C);
+            size_t r = i / C;
+            const int x = (int)(r % W);
+            r /= W;
+            const int yy = (int)(r % H);
+            const int n = (int)(r / H);
+            g = f.g[(((size_t)n * HP + yy + f.P) * WP + x + f.P) * C + c];
+        }
+        out[i] = (__bf16)((float)y[i] > 0.0f ? g : slope * g);
+    }
 }
 
 // folded gradient -> bf16 T layout (layers without GDN between two convolutions)

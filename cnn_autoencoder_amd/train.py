@@ -18,9 +18,9 @@ What the reference's training step does (``src/train_cae_ms.py:189-262``) and wh
 * ``nn.DataParallel``'s gradient reduction (``_autoencoders.py:517``): ``GradReducer``, bucketed all-reduce over
   ``torch.distributed`` (RCCL over xGMI on GPUs, gloo on CPU), one process per GPU.
 
-Variants covered: ``act_layer_type in (None, 'GDN')`` units without residual branches, batch norm, groups or
-multiscale colour layers (the canonical model and its plain variant); anything else raises ``NotImplementedError``
-under autograd.
+Variants covered: ``act_layer_type in (None, 'GDN', 'LeakyReLU', 'ReLU')`` units (the last two with their stride-1
+pre-convolutions) without residual branches, batch norm, groups or multiscale colour layers; anything else raises
+``NotImplementedError`` under autograd.
 """
 from __future__ import annotations
 
@@ -54,14 +54,17 @@ def _st():
 class LayerSpec:
     """Static description of one unit for the track functions."""
 
-    def __init__(self, cin: int, cout: int, ks: int, has_bias: bool, has_gdn: bool):
+    def __init__(self, cin: int, cout: int, ks: int, has_bias: bool, has_gdn: bool, act: int = 0, has_pre: bool = False):
         self.cin, self.cout, self.ks = int(cin), int(cout), int(ks)
         self.cin_p, self.cout_p = _pad32(cin), _pad32(cout)
         self.has_bias, self.has_gdn = bool(has_bias), bool(has_gdn)
+        # LeakyReLU (1) / ReLU (2) units: activation after the strided layer, and (has_pre) a stride-1 convolution
+        # cin -> cin + the same activation in front of it (_autoencoders.py:62-76, :187-202)
+        self.act, self.has_pre = int(act), bool(has_pre)
 
     @property
     def n_tensors(self) -> int:
-        return 1 + int(self.has_bias) + 2 * int(self.has_gdn)
+        return (1 + int(self.has_bias)) * (1 + int(self.has_pre)) + 2 * int(self.has_gdn)
 
 
 def _pack(weight: torch.Tensor, contract_dim: int, ks: int) -> torch.Tensor:
@@ -76,8 +79,16 @@ def _pack(weight: torch.Tensor, contract_dim: int, ks: int) -> torch.Tensor:
 
 
 def _split_params(specs: Sequence[LayerSpec], tensors: Sequence[torch.Tensor]):
+    """-> per layer (w, b, beta, gamma, pre_w, pre_b); flat order: [pre_w, pre_b?]? w, b?, [beta, gamma]?"""
     out, k = [], 0
     for s in specs:
+        pw = pb = None
+        if s.has_pre:
+            pw = tensors[k]
+            k += 1
+            if s.has_bias:
+                pb = tensors[k]
+                k += 1
         w = tensors[k]
         k += 1
         b = beta = gamma = None
@@ -87,7 +98,47 @@ def _split_params(specs: Sequence[LayerSpec], tensors: Sequence[torch.Tensor]):
         if s.has_gdn:
             beta, gamma = tensors[k], tensors[k + 1]
             k += 2
-        out.append((w, b, beta, gamma))
+        out.append((w, b, beta, gamma, pw, pb))
+    return out
+
+
+def _bias_p(b: Optional[torch.Tensor], cp: int, dev) -> Optional[torch.Tensor]:
+    if b is None:
+        return None
+    out = torch.zeros(cp, dtype=torch.float32, device=dev)
+    out[:b.numel()] = b.detach().float()
+    return out
+
+
+def _act_backward(g16, gext32, pad, y16, act):
+    """gradient through LeakyReLU / ReLU: g * (y > 0 ? 1 : slope), y = the activation's output; g bf16, or the fp32
+    extended-domain gradient (folded in place first) -> bf16"""
+    n, h, w, cp = y16.shape
+    out = torch.empty_like(y16)
+    _lib.check(_L().cae_t_act_backward(_ptr(g16), _ptr(gext32), pad, y16.data_ptr(), n, h, w, cp, act, out.data_ptr(), _st()))
+    return out
+
+
+def _colsum(g16, c):
+    n, h, w, cp = g16.shape
+    gb = torch.empty(cp, dtype=torch.float32, device=g16.device)
+    _lib.check(_L().cae_t_colsum(g16.data_ptr(), n * h * w, cp, gb.data_ptr(), _st()))
+    return gb[:c].clone()
+
+
+def _flat_grads(specs, per_layer):
+    """per_layer[i] = [g_w, g_b, g_beta, g_gamma, g_pre_w, g_pre_b] -> the flat order of _split_params"""
+    out: List[Optional[torch.Tensor]] = []
+    for s, (g_w, g_b, g_beta, g_gamma, g_pw, g_pb) in zip(specs, per_layer):
+        if s.has_pre:
+            out.append(g_pw)
+            if s.has_bias:
+                out.append(g_pb)
+        out.append(g_w)
+        if s.has_bias:
+            out.append(g_b)
+        if s.has_gdn:
+            out.extend([g_beta, g_gamma])
     return out
 
 
@@ -163,39 +214,43 @@ def _weight_grad(gw: torch.Tensor, spec_shape: Tuple[int, int], ks: int) -> torc
 
 
 class AnalysisFn(torch.autograd.Function):
-    """Analyzer.forward under autograd: L x [reflect conv s2 (+bias) (+GDN)] (_autoencoders.py:78-85, :29-30)."""
+    """Analyzer.forward under autograd: L x [(conv s1 + act)? reflect conv s2 (+bias) (+GDN | act)]
+    (_autoencoders.py:62-85, :29-30)."""
 
     @staticmethod
     def forward(ctx, x, specs, *tensors):
         L = _L()
         layers = _split_params(specs, tensors)
         n, _, h, w = x.shape
+        dev = x.device
         a16, _ = _from_nchw(x, specs[0].cin_p)
         saved, dims = [], []
         z32 = None
-        for i, (s, (wt, b, beta, gamma)) in enumerate(zip(specs, layers)):
+        for i, (s, (wt, b, beta, gamma, pw, pb)) in enumerate(zip(specs, layers)):
             last = i == len(specs) - 1
             oh, ow = (h + 1) // 2, (w + 1) // 2
+            a16_in, p16 = a16, None
+            if s.has_pre:  # stride-1 reflect convolution cin -> cin + activation
+                p16 = torch.empty((n, h, w, s.cin_p), dtype=torch.bfloat16, device=dev)
+                wpp, bpp = _pack(pw, 1, s.ks), _bias_p(pb, s.cin_p, dev)
+                _lib.check(L.cae_t_corr_s1(a16.data_ptr(), n, h, w, s.cin_p, wpp.data_ptr(), s.ks, 0, None, p16.data_ptr(),
+                                           s.cin_p, _ptr(bpp), s.act, _st()))
             wp = _pack(wt, 1, s.ks)
-            bias_p = None
-            if b is not None:
-                bias_p = torch.zeros(s.cout_p, dtype=torch.float32, device=x.device)
-                bias_p[:s.cout] = b.detach().float()
+            bias_p = _bias_p(b, s.cout_p, dev)
             need32 = s.has_gdn or last
-            z32 = torch.empty((n, oh, ow, s.cout_p), dtype=torch.float32, device=x.device) if need32 else None
-            z16 = None if need32 else torch.empty((n, oh, ow, s.cout_p), dtype=torch.bfloat16, device=x.device)
-            _lib.check(L.cae_t_conv_forward(a16.data_ptr(), n, h, w, s.cin_p, wp.data_ptr(), s.ks, _ptr(z32), _ptr(z16),
-                                            s.cout_p, _ptr(bias_p), _st()))
+            z32 = torch.empty((n, oh, ow, s.cout_p), dtype=torch.float32, device=dev) if need32 else None
+            z16 = None if need32 else torch.empty((n, oh, ow, s.cout_p), dtype=torch.bfloat16, device=dev)
+            main_in = p16 if p16 is not None else a16
+            _lib.check(L.cae_t_conv_forward_act(main_in.data_ptr(), n, h, w, s.cin_p, wp.data_ptr(), s.ks, _ptr(z32), _ptr(z16),
+                                                s.cout_p, _ptr(bias_p), 0 if need32 else s.act, _st()))
             f_saved = None
-            a16_in = a16
             if s.has_gdn:
                 a16, f_saved = _gdn_forward(z32, beta, gamma, False)
-            saved.append((a16_in, z32 if s.has_gdn else None, f_saved))
-            dims.append((h, w, oh, ow))
-            if s.has_gdn:
-                pass
             elif not last:
-                a16 = z16
+                a16 = z16  # (post-activation output of a LeakyReLU / ReLU unit)
+            saved.append(dict(a_in=a16_in, p=p16, z=z32 if s.has_gdn else None, f=f_saved,
+                              out=a16 if (s.act and not need32) else None))
+            dims.append((h, w, oh, ow))
             h, w = oh, ow
         y = _to_nchw(z32, specs[-1].cout)
         ctx.specs, ctx.saved, ctx.dims, ctx.layers = specs, saved, dims, [tuple(t.detach() if t is not None else None
@@ -209,80 +264,96 @@ class AnalysisFn(torch.autograd.Function):
         n = gy.shape[0]
         dev = gy.device
         g16, _ = _from_nchw(gy, specs[-1].cout_p)  # gradient with respect to the last convolution's output
-        per_layer = [[None, None, None, None] for _ in specs]
+        per_layer = [[None] * 6 for _ in specs]
+        masked = False  # g16 already went through this unit's activation (applied on the fp32 gradient: one rounding)
         for i in reversed(range(len(specs))):
             s = specs[i]
-            wt, b, _, _ = layers[i]
-            a16_in = saved[i][0]
+            wt, b, _, _, pw, pb = layers[i]
+            sv = saved[i]
             h, w, oh, ow = dims[i]
             kk = s.ks * s.ks
+            P = s.ks // 2
+            if sv['out'] is not None and not masked:  # through the unit's activation
+                g16 = _act_backward(g16, None, 0, sv['out'], s.act)
+            masked = False
+            main_in = sv['p'] if s.has_pre else sv['a_in']
             gw = torch.empty((kk, s.cin_p, s.cout_p), dtype=torch.float32, device=dev)
-            _lib.check(L.cae_t_wgrad(a16_in.data_ptr(), n, h, w, s.cin_p, g16.data_ptr(), oh, ow, s.cout_p, s.ks, 1,
+            _lib.check(L.cae_t_wgrad(main_in.data_ptr(), n, h, w, s.cin_p, g16.data_ptr(), oh, ow, s.cout_p, s.ks, 1,
                                      gw.data_ptr(), _st()))
             per_layer[i][0] = _weight_grad(gw, (s.cout, s.cin), s.ks)
             if b is not None:
-                gb = torch.empty(s.cout_p, dtype=torch.float32, device=dev)
-                _lib.check(L.cae_t_colsum(g16.data_ptr(), n * oh * ow, s.cout_p, gb.data_ptr(), _st()))
-                per_layer[i][1] = gb[:s.cout].clone()
-            if i == 0:
+                per_layer[i][1] = _colsum(g16, s.cout)
+            if i == 0 and not s.has_pre:
                 break  # (the image itself needs no gradient)
-            P = s.ks // 2
             wp_d = _pack(wt, 0, s.ks)
             gext = torch.empty((n, h + 2 * P, w + 2 * P, s.cin_p), dtype=torch.float32, device=dev)
             _lib.check(L.cae_t_conv_dgrad_ext(g16.data_ptr(), n, oh, ow, s.cout_p, wp_d.data_ptr(), s.ks, h, w,
                                               gext.data_ptr(), s.cin_p, _st()))
+            if s.has_pre:
+                gu16 = _act_backward(None, gext, P, sv['p'], s.act)  # fold + activation mask: gradient at the pre-convolution's output
+                gwp = torch.empty((kk, s.cin_p, s.cin_p), dtype=torch.float32, device=dev)
+                _lib.check(L.cae_t_wgrad_s1(sv['a_in'].data_ptr(), n, h, w, s.cin_p, gu16.data_ptr(), s.cin_p, s.ks, 1,
+                                            gwp.data_ptr(), _st()))
+                per_layer[i][4] = _weight_grad(gwp, (s.cin, s.cin), s.ks)
+                if pb is not None:
+                    per_layer[i][5] = _colsum(gu16, s.cin)
+                if i == 0:
+                    break
+                wpp_d = _pack(pw, 0, s.ks)
+                gext = torch.empty((n, h + 2 * P, w + 2 * P, s.cin_p), dtype=torch.float32, device=dev)
+                _lib.check(L.cae_t_corr_s1(gu16.data_ptr(), n, h, w, s.cin_p, wpp_d.data_ptr(), s.ks, 1, gext.data_ptr(), None,
+                                           s.cin_p, None, 0, _st()))
             if specs[i - 1].has_gdn:
-                _, z_prev, f_prev = saved[i - 1]
-                _, _, beta_p, gamma_p = layers[i - 1]
+                z_prev, f_prev = saved[i - 1]['z'], saved[i - 1]['f']
+                _, _, beta_p, gamma_p, _, _ = layers[i - 1]
                 g16, g_beta, g_gamma = _gdn_backward(z_prev, gext, P, beta_p, gamma_p, False, f_prev)
                 per_layer[i - 1][2], per_layer[i - 1][3] = g_beta, g_gamma
+            elif saved[i - 1]['out'] is not None:  # reflect fold + the previous unit's activation on the fp32 gradient
+                g16 = _act_backward(None, gext, P, saved[i - 1]['out'], specs[i - 1].act)
+                masked = True
             else:
                 g16 = torch.empty((n, h, w, s.cin_p), dtype=torch.bfloat16, device=dev)
                 _lib.check(L.cae_t_fold_to_bf16(gext.data_ptr(), n, h, w, P, s.cin_p, g16.data_ptr(), _st()))
-        out: List[Optional[torch.Tensor]] = []
-        for i, s in enumerate(specs):
-            g_w, g_b, g_beta, g_gamma = per_layer[i]
-            out.append(g_w)
-            if s.has_bias:
-                out.append(g_b)
-            if s.has_gdn:
-                out.extend([g_beta, g_gamma])
-        return (None, None, *out)
+        return (None, None, *_flat_grads(specs, per_layer))
 
 
 class SynthesisFn(torch.autograd.Function):
-    """Synthesizer.forward under autograd: L x [conv-transpose s2 (+bias) (+IGDN)] (_autoencoders.py:204-211)."""
+    """Synthesizer.forward under autograd: L x [(conv-transpose s1 + act)? conv-transpose s2 (+bias) (+IGDN | act)]
+    (_autoencoders.py:187-211)."""
 
     @staticmethod
     def forward(ctx, yq, specs, *tensors):
         L = _L()
         layers = _split_params(specs, tensors)
         n, _, h, w = yq.shape
+        dev = yq.device
         a16, _ = _from_nchw(yq, specs[0].cin_p)
         saved, dims = [], []
         z32 = None
-        for i, (s, (wt, b, beta, gamma)) in enumerate(zip(specs, layers)):
+        for i, (s, (wt, b, beta, gamma, pw, pb)) in enumerate(zip(specs, layers)):
             last = i == len(specs) - 1
+            a16_in, p16 = a16, None
+            if s.has_pre:  # ConvTranspose2d(cin, cin, k, stride 1, padding k//2) + activation
+                p16 = torch.empty((n, h, w, s.cin_p), dtype=torch.bfloat16, device=dev)
+                wpp, bpp = _pack(pw, 0, s.ks), _bias_p(pb, s.cin_p, dev)
+                _lib.check(L.cae_t_corr_s1(a16.data_ptr(), n, h, w, s.cin_p, wpp.data_ptr(), s.ks, 2, None, p16.data_ptr(),
+                                           s.cin_p, _ptr(bpp), s.act, _st()))
             wp = _pack(wt, 0, s.ks)
-            bias_p = None
-            if b is not None:
-                bias_p = torch.zeros(s.cout_p, dtype=torch.float32, device=yq.device)
-                bias_p[:s.cout] = b.detach().float()
+            bias_p = _bias_p(b, s.cout_p, dev)
             need32 = s.has_gdn or last
-            z32 = torch.empty((n, 2 * h, 2 * w, s.cout_p), dtype=torch.float32, device=yq.device) if need32 else None
-            z16 = None if need32 else torch.empty((n, 2 * h, 2 * w, s.cout_p), dtype=torch.bfloat16, device=yq.device)
-            _lib.check(L.cae_t_deconv_forward(a16.data_ptr(), n, h, w, s.cin_p, wp.data_ptr(), s.ks, _ptr(z32), _ptr(z16),
-                                              s.cout_p, _ptr(bias_p), _st()))
+            z32 = torch.empty((n, 2 * h, 2 * w, s.cout_p), dtype=torch.float32, device=dev) if need32 else None
+            z16 = None if need32 else torch.empty((n, 2 * h, 2 * w, s.cout_p), dtype=torch.bfloat16, device=dev)
+            main_in = p16 if p16 is not None else a16
+            _lib.check(L.cae_t_deconv_forward_act(main_in.data_ptr(), n, h, w, s.cin_p, wp.data_ptr(), s.ks, _ptr(z32),
+                                                  _ptr(z16), s.cout_p, _ptr(bias_p), 0 if need32 else s.act, _st()))
             f_saved = None
-            a16_in = a16
             if s.has_gdn:
                 a16, f_saved = _gdn_forward(z32, beta, gamma, True)
-            saved.append((a16_in, z32 if s.has_gdn else None, f_saved))
-            dims.append((h, w))
-            if s.has_gdn:
-                pass
             elif not last:
                 a16 = z16
+            saved.append(dict(a_in=a16_in, p=p16, z=z32 if s.has_gdn else None, f=f_saved,
+                              out=a16 if (s.act and not need32) else None))
+            dims.append((h, w))
             h, w = 2 * h, 2 * w
         x_r = _to_nchw(z32, specs[-1].cout)
         ctx.specs, ctx.saved, ctx.dims = specs, saved, dims
@@ -297,49 +368,64 @@ class SynthesisFn(torch.autograd.Function):
         n = gx.shape[0]
         dev = gx.device
         g16, _ = _from_nchw(gx, specs[-1].cout_p)  # gradient with respect to the last layer's output
-        per_layer = [[None, None, None, None] for _ in specs]
+        per_layer = [[None] * 6 for _ in specs]
         g_in = None
+        masked = False  # g16 already went through this unit's activation (applied on the fp32 gradient: one rounding)
         for i in reversed(range(len(specs))):
             s = specs[i]
-            wt, b, _, _ = layers[i]
-            a16_in = saved[i][0]
+            wt, b, _, _, pw, pb = layers[i]
+            sv = saved[i]
             h, w = dims[i]
             kk = s.ks * s.ks
+            if sv['out'] is not None and not masked:  # through the unit's activation
+                g16 = _act_backward(g16, None, 0, sv['out'], s.act)
+            masked = False
+            main_in = sv['p'] if s.has_pre else sv['a_in']
             gw = torch.empty((kk, s.cout_p, s.cin_p), dtype=torch.float32, device=dev)
-            _lib.check(L.cae_t_wgrad(g16.data_ptr(), n, 2 * h, 2 * w, s.cout_p, a16_in.data_ptr(), h, w, s.cin_p, s.ks, 0,
+            _lib.check(L.cae_t_wgrad(g16.data_ptr(), n, 2 * h, 2 * w, s.cout_p, main_in.data_ptr(), h, w, s.cin_p, s.ks, 0,
                                      gw.data_ptr(), _st()))
             per_layer[i][0] = _weight_grad(gw, (s.cin, s.cout), s.ks)
             if b is not None:
-                gb = torch.empty(s.cout_p, dtype=torch.float32, device=dev)
-                _lib.check(L.cae_t_colsum(g16.data_ptr(), n * 4 * h * w, s.cout_p, gb.data_ptr(), _st()))
-                per_layer[i][1] = gb[:s.cout].clone()
-            if i == 0 and not ctx.need_input_grad:
+                per_layer[i][1] = _colsum(g16, s.cout)
+            if i == 0 and not ctx.need_input_grad and not s.has_pre:
                 break
             wp_d = _pack(wt, 1, s.ks)
             prev_gdn = i > 0 and specs[i - 1].has_gdn
-            want32 = prev_gdn or i == 0
+            prev_act = i > 0 and saved[i - 1]['out'] is not None
+            want32 = prev_gdn or prev_act or i == 0 or s.has_pre  # (fp32 into an activation's backward: one rounding)
             gx32 = torch.empty((n, h, w, s.cin_p), dtype=torch.float32, device=dev) if want32 else None
             gx16 = None if want32 else torch.empty((n, h, w, s.cin_p), dtype=torch.bfloat16, device=dev)
             _lib.check(L.cae_t_deconv_dgrad(g16.data_ptr(), n, h, w, s.cout_p, wp_d.data_ptr(), s.ks, _ptr(gx32), _ptr(gx16),
                                             s.cin_p, _st()))
+            if s.has_pre:
+                gu16 = _act_backward(None, gx32, 0, sv['p'], s.act)  # gradient at the pre-convolution's output
+                gwp = torch.empty((kk, s.cin_p, s.cin_p), dtype=torch.float32, device=dev)
+                _lib.check(L.cae_t_wgrad_s1(gu16.data_ptr(), n, h, w, s.cin_p, sv['a_in'].data_ptr(), s.cin_p, s.ks, 0,
+                                            gwp.data_ptr(), _st()))
+                per_layer[i][4] = _weight_grad(gwp, (s.cin, s.cin), s.ks)
+                if pb is not None:
+                    per_layer[i][5] = _colsum(gu16, s.cin)
+                if i == 0 and not ctx.need_input_grad:
+                    break
+                wpp_d = _pack(pw, 1, s.ks)
+                want32 = prev_gdn or prev_act or i == 0
+                gx32 = torch.empty((n, h, w, s.cin_p), dtype=torch.float32, device=dev) if want32 else None
+                gx16 = None if want32 else torch.empty((n, h, w, s.cin_p), dtype=torch.bfloat16, device=dev)
+                _lib.check(L.cae_t_corr_s1(gu16.data_ptr(), n, h, w, s.cin_p, wpp_d.data_ptr(), s.ks, 3, _ptr(gx32), _ptr(gx16),
+                                           s.cin_p, None, 0, _st()))
             if i == 0:
                 g_in = _to_nchw(gx32, s.cin)
             elif prev_gdn:
-                _, z_prev, f_prev = saved[i - 1]
-                _, _, beta_p, gamma_p = layers[i - 1]
+                z_prev, f_prev = saved[i - 1]['z'], saved[i - 1]['f']
+                _, _, beta_p, gamma_p, _, _ = layers[i - 1]
                 g16, g_beta, g_gamma = _gdn_backward(z_prev, gx32, 0, beta_p, gamma_p, True, f_prev)
                 per_layer[i - 1][2], per_layer[i - 1][3] = g_beta, g_gamma
+            elif prev_act:  # the previous unit's activation on the fp32 gradient
+                g16 = _act_backward(None, gx32, 0, saved[i - 1]['out'], specs[i - 1].act)
+                masked = True
             else:
                 g16 = gx16
-        out: List[Optional[torch.Tensor]] = []
-        for i, s in enumerate(specs):
-            g_w, g_b, g_beta, g_gamma = per_layer[i]
-            out.append(g_w)
-            if s.has_bias:
-                out.append(g_b)
-            if s.has_gdn:
-                out.extend([g_beta, g_gamma])
-        return (g_in, None, *out)
+        return (g_in, None, *_flat_grads(specs, per_layer))
 
 
 def _track_inputs(track, units, synthesis: bool):
@@ -349,13 +435,18 @@ def _track_inputs(track, units, synthesis: bool):
     if getattr(track, 'multiscale_analysis', False):
         raise NotImplementedError('training with multiscale colour layers is not built')
     for u in units:
-        if isinstance(u, _ResidualUnit) or u.pre is not None or u.act_code:
-            raise NotImplementedError('training is built for GDN / activation-free units (no residual, LeakyReLU, ReLU)')
-        if u.main_bn_index is not None or u.main.groups != 1:
+        if isinstance(u, _ResidualUnit):
+            raise NotImplementedError('training of residual units is not built')
+        if u.main_bn_index is not None or u.pre_bn_index is not None or u.main.groups != 1:
             raise NotImplementedError('training with BatchNorm or grouped layers is not built')
         conv = u.main
         has_gdn = u.gdn is not None
-        specs.append(LayerSpec(conv.in_channels, conv.out_channels, conv.kernel_size, conv.bias is not None, has_gdn))
+        specs.append(LayerSpec(conv.in_channels, conv.out_channels, conv.kernel_size, conv.bias is not None, has_gdn,
+                               act=u.act_code, has_pre=u.pre is not None))
+        if u.pre is not None:  # LeakyReLU / ReLU units: the stride-1 convolution in front (same bias setting as the layer)
+            tensors.append(u.pre.weight)
+            if conv.bias is not None:
+                tensors.append(u.pre.bias)
         tensors.append(conv.weight)
         if conv.bias is not None:
             tensors.append(conv.bias)

@@ -284,6 +284,25 @@ int cae_t_gdn_forward(const float *z32, long pixels, int cp, const float *beta, 
 int cae_t_gdn_backward(const float *z32, const float *gext32, int n, int h, int w, int pad, int cp, const float *beta,
                        const float *gamma, const float *gamma_t, int inverse, float *gn_ws32, float *gzd_ws32, float *gz32,
                        void *gz16, float *ggamma, float *gbeta, void *stream);
+/* LeakyReLU / ReLU units under autograd (DownsamplingUnit _autoencoders.py:62-76,90-92; UpsamplingUnit :187-202,216-218):
+ * the strided layers with the activation (1 LeakyReLU(0.01), 2 ReLU) in their epilogue; the stride-1 pre-convolutions as
+ * cae_t_corr_s1 -- mode 0 analysis forward (reflect), 1 its data gradient on the extended domain (h + 2P) x (w + 2P),
+ * 2 synthesis forward (ConvTranspose2d stride 1, padding k//2), 3 its data gradient; the packed weights carry the
+ * contraction (cae_t_pack_weights: contract_dim 1 for modes 0 and 3, 0 for modes 1 and 2) --, their weight gradient
+ * cae_t_wgrad_s1 (x and y of equal size; analysis: x = input, reflect; synthesis: x = output gradient, zeros, y = input),
+ * and the activation's backward cae_t_act_backward: out = g * (y > 0 ? 1 : slope) with y the activation's OUTPUT and g
+ * either bf16 (g16) or the fp32 extended-domain gradient gext32, whose reflect fold is applied in place first. */
+int cae_t_conv_forward_act(const void *x16, int n, int h, int w, int cin_p, const void *packed, int ks, float *z32, void *z16,
+                           int cout_p, const float *bias, int act, void *stream);
+int cae_t_deconv_forward_act(const void *x16, int n, int h, int w, int cin_p, const void *packed, int ks, float *z32, void *z16,
+                             int cout_p, const float *bias, int act, void *stream);
+int cae_t_corr_s1(const void *x16, int n, int h, int w, int ck, const void *packed, int ks, int mode, float *out32, void *out16,
+                  int cn, const float *bias, int act, void *stream);
+int cae_t_wgrad_s1(const void *x16, int n, int h, int w, int ca, const void *y16, int cb, int ks, int reflect, float *gw32,
+                   void *stream);
+int cae_t_act_backward(const void *g16, float *gext32, int pad, const void *y16, int n, int h, int w, int cp, int act,
+                       void *out16, void *stream);
+
 /* Fused forms (csrc/cae_train_gdn.hpp; cp <= 128): the forward also saves the per-element factor f (y = z f: n^(-1/2),
  * IGDN n^(1/2)) in the register order the backward reads back -- f_saved holds cae_t_gdn_saved_elems(pixels, cp) floats
  * (0: shape not built) -- and the backward is ONE kernel: g_z (bf16), g_gamma, g_beta from z, f and the gradient with

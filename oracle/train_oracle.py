@@ -83,22 +83,44 @@ def _g(x, bf16):
     return _GradRound.apply(x) if bf16 else x
 
 
-def analysis(x: torch.Tensor, layers: Sequence[dict], bf16: bool = True) -> torch.Tensor:
-    """layers[i] = {'weight', 'bias'?, 'beta'?, 'gamma'?} (stored parameters, leaf tensors with requires_grad)"""
+def _act(x: torch.Tensor, act: Optional[str]) -> torch.Tensor:
+    if act == 'LeakyReLU':
+        return F.leaky_relu(x, 0.01)
+    if act == 'ReLU':
+        return F.relu(x)
+    return x
+
+
+def analysis(x: torch.Tensor, layers: Sequence[dict], bf16: bool = True, act: Optional[str] = None) -> torch.Tensor:
+    """layers[i] = {'weight', 'bias'?, 'beta'?, 'gamma'?, 'pre_weight'?, 'pre_bias'?} (stored parameters, leaf tensors
+    with requires_grad).  LeakyReLU / ReLU units (`act`; DownsamplingUnit, _autoencoders.py:62-92): a stride-1 reflect
+    convolution + activation in front of the strided layer, the activation after it; the last unit has neither."""
     fx = x
-    for L in layers:
+    for i, L in enumerate(layers):
+        if L.get('pre_weight') is not None:
+            k = L['pre_weight'].shape[-1]
+            u = F.conv2d(F.pad(_r(fx, bf16), (k // 2,) * 4, mode='reflect'), _r(L['pre_weight'], bf16), L.get('pre_bias'))
+            fx = _act(_g(u, bf16), act)
         fx = _g(O.reflect_conv_s2(_r(fx, bf16), _r(L['weight'], bf16), L.get('bias')), bf16)
         if L.get('beta') is not None:
             fx = gdn(fx, L['beta'], L['gamma'], False)
+        elif act is not None and i < len(layers) - 1:
+            fx = _act(fx, act)
     return fx
 
 
-def synthesis(y: torch.Tensor, layers: Sequence[dict], bf16: bool = True) -> torch.Tensor:
+def synthesis(y: torch.Tensor, layers: Sequence[dict], bf16: bool = True, act: Optional[str] = None) -> torch.Tensor:
     fx = y
-    for L in layers:
+    for i, L in enumerate(layers):
+        if L.get('pre_weight') is not None:  # ConvTranspose2d(cin, cin, k, stride 1, padding k//2) (UpsamplingUnit :187-202)
+            k = L['pre_weight'].shape[-1]
+            u = F.conv_transpose2d(_r(fx, bf16), _r(L['pre_weight'], bf16), L.get('pre_bias'), stride=1, padding=k // 2)
+            fx = _act(_g(u, bf16), act)
         fx = _g(O.deconv_s2(_r(fx, bf16), _r(L['weight'], bf16), L.get('bias')), bf16)
         if L.get('beta') is not None:
             fx = gdn(fx, L['beta'], L['gamma'], True)
+        elif act is not None and i < len(layers) - 1:
+            fx = _act(fx, act)
     return fx
 
 

@@ -178,9 +178,16 @@ def _models(cae, cfg, seed):
     state = synth.synthetic_state(cfg, seed=seed)
     model = cae.autoencoder_from_state_dict(state, train=True)
     leaf = lambda t: None if t is None else t.detach().clone().requires_grad_(True)  # noqa: E731
-    layers = {part: [{k: leaf(v) for k, v in l.items() if k in ('weight', 'bias', 'beta', 'gamma')}
+    layers = {part: [{k: leaf(v) for k, v in l.items() if k in ('weight', 'bias', 'beta', 'gamma', 'pre_weight', 'pre_bias')}
                      for l in oracle_layers(state, part)] for part in ('encoder', 'decoder')}
     return state, model, layers
+
+
+def _param_names(l):
+    """(oracle key, state-dict suffix) pairs of a unit: with a pre-convolution the strided layer is model.2"""
+    if l.get('pre_weight') is not None:
+        return (('pre_weight', 'model.0.weight'), ('pre_bias', 'model.0.bias'), ('weight', 'model.2.weight'), ('bias', 'model.2.bias'))
+    return (('weight', 'model.0.weight'), ('bias', 'model.0.bias'), ('beta', 'model.1.beta'), ('gamma', 'model.1.gamma'))
 
 
 def _named_grads(module, track):
@@ -194,7 +201,12 @@ def _named_grads(module, track):
 @pytest.mark.parametrize('cfgkw,shape', [(dict(channels_net=32, channels_bn=48, compression_level=3), (2, 40, 56)),
                                          (dict(channels_net=128, channels_bn=192, compression_level=4), (1, 64, 64)),
                                          (dict(channels_net=32, channels_bn=48, compression_level=2, act_layer_type=None, bias=True,
-                                               kernel_size=5), (2, 37, 45))])
+                                               kernel_size=5), (2, 37, 45)),
+                                         # the reference's default activation family: stride-1 pre-convolutions + LeakyReLU / ReLU
+                                         (dict(channels_net=32, channels_bn=48, compression_level=3, act_layer_type='LeakyReLU',
+                                               bias=True), (2, 40, 56)),
+                                         (dict(channels_net=64, channels_bn=48, compression_level=2, act_layer_type='ReLU',
+                                               kernel_size=5), (1, 37, 45))])
 def test_track_gradients_match_the_restatement(cae, cfgkw, shape):
     from cnn_autoencoder_amd import synth
     from oracle import train_oracle as T
@@ -208,15 +220,17 @@ def test_track_gradients_match_the_restatement(cae, cfgkw, shape):
     y = enc(x.cuda())
     gy = torch.randn_like(y.detach()).cpu()
     y.backward(gy.cuda())
-    y_ref = T.analysis(x, layers['encoder'], bf16=True)
+    act = cfg['act_layer_type'] if cfg['act_layer_type'] in ('LeakyReLU', 'ReLU') else None
+    y_ref = T.analysis(x, layers['encoder'], bf16=True, act=act)
     y_ref.backward(gy)
     assert y.shape == y_ref.shape and rel(y.detach(), y_ref.detach()) < 1e-3
-    y32 = T.analysis(x, [{k: (v.detach() if v is not None else None) for k, v in l.items()} for l in layers['encoder']], bf16=False)
+    y32 = T.analysis(x, [{k: (v.detach() if v is not None else None) for k, v in l.items()} for l in layers['encoder']], bf16=False,
+                     act=act)
     assert rel(y.detach(), y32) < 3e-2
     got = _named_grads(enc, 'analysis_track')
     assert got, 'no gradients reached the encoder parameters'
     for i, l in enumerate(layers['encoder']):
-        for key, sub in (('weight', 'model.0.weight'), ('bias', 'model.0.bias'), ('beta', 'model.1.beta'), ('gamma', 'model.1.gamma')):
+        for key, sub in _param_names(l):
             if l.get(key) is not None:
                 name = f'analysis_track.{i}.{sub}'
                 # The restatement rounds to bf16 at the kernels' rounding points, so the two sides differ by summation
@@ -233,14 +247,14 @@ def test_track_gradients_match_the_restatement(cae, cfgkw, shape):
     x_r, _ = dec(yq_dev)
     gx = torch.randn_like(x_r[0].detach()).cpu()
     x_r[0].backward(gx.cuda())
-    xr_ref = T.synthesis(yq, layers['decoder'], bf16=True)
+    xr_ref = T.synthesis(yq, layers['decoder'], bf16=True, act=act)
     xr_ref.backward(gx)
     scale = max(1.0, float(xr_ref.abs().max()))
     assert float((x_r[0].detach().cpu() - xr_ref.detach()).abs().max()) / scale < 1e-3
     assert rel(yq_dev.grad, yq.grad) < 1e-3
     got = _named_grads(dec, 'synthesis_track')
     for i, l in enumerate(layers['decoder']):
-        for key, sub in (('weight', 'model.0.weight'), ('bias', 'model.0.bias'), ('beta', 'model.1.beta'), ('gamma', 'model.1.gamma')):
+        for key, sub in _param_names(l):
             if l.get(key) is not None:
                 name = f'synthesis_track.{i}.{sub}'
                 assert rel(got[name], l[key].grad) < 1e-3, name
