@@ -409,7 +409,7 @@ def main():
                 'f16x3': {'analysis.1': 'conv_s2_f16_kernel<3, 4, true>@2097152',
                           'synthesis.2': 'deconv_s2_f16_kernel<3, 4, 8, 1, true>@4194304'}}[args.precision]
         key = keys.get(dom['name'].split(' ')[0])
-        for name in ('r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
+        for name in ('r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
             try:
                 tj = json.load(open(os.path.join(ROOT, 'profiles', name)))
                 if key and B == 32 and H == 1024 and key in tj[args.precision]:
