@@ -102,6 +102,8 @@ SYMBOLS = {
                                       c_void_p, c_void_p]),
     'cae_t_density_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float,
                                        c_void_p, c_void_p, c_void_p]),
+    'cae_t_clip_adam': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'cae_cpu_budget': (c_int, []),
     'cae_coder_lockstep': (c_int, []),
     'cae_coder_threads': (c_int, [c_int, c_int]),

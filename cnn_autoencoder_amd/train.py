@@ -508,6 +508,69 @@ def setup_optim(model: Dict[str, nn.Module], trainable_modules: Sequence[str] = 
     return opts
 
 
+_OPTIM_WS: Dict[torch.device, torch.Tensor] = {}
+
+
+def fused_clip_adam(optimizers: Dict[str, torch.optim.Optimizer], max_norm: float = 1.0) -> bool:
+    """`for opt: clip_grad_norm_(params, max_norm); opt.step(); opt.zero_grad()` (train_cae_ms.py:221-230) for ALL
+    optimisers in two launches (cae_t_clip_adam), on the optimisers' own state tensors (exp_avg, exp_avg_sq, step), so
+    `state_dict()` / checkpoints stay torch.optim.Adam's.  -> False (nothing done) unless every optimiser is a plain
+    torch.optim.Adam (one parameter group, no amsgrad / maximize / capturable) over contiguous fp32 CUDA parameters;
+    CAE_FUSED_OPTIM=0 disables it."""
+    if os.environ.get('CAE_FUSED_OPTIM', '1') == '0' or len(optimizers) > 8:
+        return False
+    items = []  # (p, grad, exp_avg, exp_avg_sq, group index)
+    groups = []
+    for gi, opt in enumerate(optimizers.values()):
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return False
+        g = opt.param_groups[0]
+        if g.get('amsgrad') or g.get('maximize') or g.get('capturable') or g.get('differentiable') or \
+                not isinstance(g['lr'], (int, float)):
+            return False
+        live = [p for p in g['params'] if p.grad is not None]
+        for p in live:
+            if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or p.grad.dtype != torch.float32:
+                return False
+        groups.append((opt, g, live))
+    for gi, (opt, g, live) in enumerate(groups):
+        for p in live:
+            st = opt.state[p]
+            if len(st) == 0:  # as torch.optim.Adam initialises it lazily
+                st['step'] = torch.tensor(0.0)
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if not (st['exp_avg'].is_contiguous() and st['exp_avg_sq'].is_contiguous()) or st['step'].is_cuda:
+                return False
+            items.append((p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), st['exp_avg'], st['exp_avg_sq'], gi))
+    if not items or len(items) > 64:
+        return False
+    n, G = len(items), len(groups)
+    steps = []
+    for opt, g, live in groups:
+        steps.append(int(opt.state[live[0]]['step'].item()) + 1 if live else 1)
+        for p in live:
+            opt.state[p]['step'] += 1
+    vp = lambda k: (ctypes.c_void_p * n)(*[it[k].data_ptr() for it in items])  # noqa: E731
+    numel = (ctypes.c_int * n)(*[it[0].numel() for it in items])
+    grp = (ctypes.c_int * n)(*[it[4] for it in items])
+    fl = lambda vals: (ctypes.c_float * G)(*vals)  # noqa: E731
+    chunks = sum((it[0].numel() + 2047) // 2048 for it in items)
+    dev = items[0][0].device
+    ws = _OPTIM_WS.get(dev)
+    if ws is None or ws.numel() < chunks:
+        ws = _OPTIM_WS[dev] = torch.empty(max(chunks, 1024), dtype=torch.float32, device=dev)
+    _lib.check(_L().cae_t_clip_adam(
+        n, vp(0), vp(1), vp(2), vp(3), numel, grp, G, fl([g['lr'] for _, g, _ in groups]),
+        fl([g['betas'][0] for _, g, _ in groups]), fl([g['betas'][1] for _, g, _ in groups]), fl([g['eps'] for _, g, _ in groups]),
+        fl([g['weight_decay'] for _, g, _ in groups]), fl([max_norm] * G), (ctypes.c_int * G)(*steps), ws.data_ptr(), ws.numel(),
+        _st()))
+    for opt, g, _ in groups:  # zero_grad(set_to_none=True)
+        for p in g['params']:
+            p.grad = None
+    return True
+
+
 def train_step(x: torch.Tensor, model, criterion, optimizers, forward_func=None, reducer: 'GradReducer' = None):
     """One iteration of the reference's hot loop (train_cae_ms.py:209-230).  -> loss_dict (detached scalars)"""
     from .criteria import setup_forward_func
@@ -520,10 +583,11 @@ def train_step(x: torch.Tensor, model, criterion, optimizers, forward_func=None,
         torch.mean(loss_dict['entropy_loss']).backward()
     if reducer is not None:
         reducer.reduce()
-    for opt in optimizers.values():
-        nn.utils.clip_grad_norm_(opt.param_groups[0]['params'], max_norm=1.0)
-        opt.step()
-        opt.zero_grad()
+    if not fused_clip_adam(optimizers, max_norm=1.0):
+        for opt in optimizers.values():
+            nn.utils.clip_grad_norm_(opt.param_groups[0]['params'], max_norm=1.0)
+            opt.step()
+            opt.zero_grad()
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
 
 

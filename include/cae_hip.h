@@ -333,6 +333,18 @@ int cae_t_density_backward(const float *out, const float *g_lik, const float *g_
 int cae_t_reparam_forward(const float *x, long n, float bound, float pedestal, float *out, void *stream);
 int cae_t_reparam_backward(const float *x, const float *g, long n, float bound, float *gx, void *stream);
 
+/* One clip + Adam step over all parameters of a training step (train_cae_ms.py:221-230: per optimiser
+ * clip_grad_norm_(params, max_norm) then torch.optim.Adam.step(), no amsgrad) in two launches.  A group = one optimiser:
+ * tensors ordered by group; per group lr, betas, eps, weight_decay, max_norm (<= 0: no clipping) and the 1-based step
+ * count of THIS step (bias corrections).  All pointers are device pointers to fp32; partial_ws holds one float per
+ * 2048-element chunk (sum over tensors of ceil(numel / 2048)); deterministic (no atomics). */
+#define CAE_OPTIM_MAX_TENSORS 64
+#define CAE_OPTIM_MAX_GROUPS 8
+int cae_t_clip_adam(int ntensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                    float *const *exp_avg_sq, const int *numel, const int *group, int ngroups, const float *lr,
+                    const float *beta1, const float *beta2, const float *eps, const float *weight_decay,
+                    const float *max_norm, const int *step, float *partial_ws, size_t partial_elems, void *stream);
+
 /* ---- host entropy coding ---------------------------------------------------------------
  * Replace compressai._CXX.pmf_to_quantized_cdf and compressai.ans.RansEncoder /
  * RansDecoder (encode_with_indexes / decode_with_indexes), reached from

@@ -260,6 +260,51 @@ def test_track_gradients_match_the_restatement(cae, cfgkw, shape):
                 assert rel(got[name], l[key].grad) < 1e-3, name
 
 
+def test_fused_clip_adam_equals_the_torch_loop(cae, monkeypatch):
+    """cae_t_clip_adam (all optimisers of a step in two launches) against the reference's loop -- clip_grad_norm_(1.0),
+    torch.optim.Adam.step(), zero_grad() per optimiser (train_cae_ms.py:221-230) -- on the same gradients, three steps:
+    parameters and the optimisers' own state (exp_avg, exp_avg_sq, step) agree."""
+    from cnn_autoencoder_amd import train
+    torch.manual_seed(3)
+    shapes = [(128, 128, 3, 3), (128,), (128, 128), (5000,), (48, 1, 3), (7,)]
+
+    def build():
+        ps = [torch.nn.Parameter(torch.randn(*s, device='cuda') * 0.1) for s in shapes]
+        opts = {'a': torch.optim.Adam([dict(params=ps[:3], lr=1e-3, weight_decay=0.0)]),
+                'b': torch.optim.Adam([dict(params=ps[3:5], lr=3e-3, weight_decay=0.01)], betas=(0.8, 0.95)),
+                'c_aux': torch.optim.Adam([dict(params=ps[5:], lr=1e-2)])}
+        return ps, opts
+    ps_a, opts_a = build()
+    ps_b, opts_b = build()
+    for a, b in zip(ps_a, ps_b):
+        b.data.copy_(a.data)
+    for step in range(3):
+        grads = [torch.randn_like(p) * (10.0 if step == 1 else 0.01) for p in ps_a]  # step 1: the clip is active
+        for p, g in zip(ps_a, grads):
+            p.grad = g.clone()
+        for p, g in zip(ps_b, grads):
+            p.grad = g.clone()
+        monkeypatch.setenv('CAE_FUSED_OPTIM', '0')
+        assert not train.fused_clip_adam(opts_a)
+        for opt in opts_a.values():
+            torch.nn.utils.clip_grad_norm_(opt.param_groups[0]['params'], max_norm=1.0)
+            opt.step()
+            opt.zero_grad()
+        monkeypatch.setenv('CAE_FUSED_OPTIM', '1')
+        assert train.fused_clip_adam(opts_b)
+        assert all(p.grad is None for p in ps_b)
+        for a, b in zip(ps_a, ps_b):
+            assert rel(b.detach(), a.detach()) < 2e-6
+    for (ka, oa), (kb, ob) in zip(opts_a.items(), opts_b.items()):
+        for pa, pb in zip(oa.param_groups[0]['params'], ob.param_groups[0]['params']):
+            sa, sb = oa.state[pa], ob.state[pb]
+            assert float(sa['step']) == float(sb['step']) == 3.0
+            # (the clip coefficient comes from another fp32 summation order of 1.6e5 squares: ~5e-6, squared in exp_avg_sq)
+            assert rel(sb['exp_avg'], sa['exp_avg']) < 2e-5 and rel(sb['exp_avg_sq'], sa['exp_avg_sq']) < 5e-5
+    # anything but plain Adam keeps the torch loop
+    assert not train.fused_clip_adam({'x': torch.optim.SGD(ps_b[:1], lr=0.1)})
+
+
 def test_twenty_training_steps_follow_the_restatement(cae):
     """train.train_step (forward_func -> GeneralLoss -> backward -> aux backward -> clip 1.0 -> per-module Adam, the
     quantiles in the `_aux` optimiser) against the same loop on the CPU restatement, same noise: the loss curve matches
