@@ -89,6 +89,11 @@ SYMBOLS = {
                                c_int, c_void_p]),
     'cae_t_wgrad_s1': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_t_act_backward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cae_t_im2col_s2': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cae_t_col2im_s2': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cae_t_pointwise': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                 c_void_p]),
+    'cae_t_wgrad_pointwise': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cae_t_gdn_saved_elems': (c_size_t, [ctypes.c_long, c_int]),
     'cae_t_gdn_forward_save': (c_int, [c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'cae_t_gdn_backward_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,

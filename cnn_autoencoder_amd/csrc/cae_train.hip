@@ -307,6 +307,9 @@ int launch_gdn_fused(const GdnFusedArgs &a, int cp, bool backward, hipStream_t s
 
 }  // namespace
 
+static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const void *ysmall16, int oh, int ow, int cb, int ks,
+                      int reflect, int S, float *gw32, void *stream);
+
 extern "C" {
 
 size_t cae_t_packed_bytes(int contract_channels, int out_channels, int kernel_size) {
@@ -378,6 +381,61 @@ int cae_t_corr_s1(const void *x16, int n, int h, int w, int ck, const void *pack
     return stride1_corr(x16, n, h, w, ck, packed, ks, mode, out32, out16, cn, bias, act, (hipStream_t)stream);
 }
 
+int cae_t_pointwise(const void *x16, int n, int h, int w, int ck, const void *packed, float *out32, void *out16, int cn,
+                    const float *bias, int act, void *stream) {
+    if (!x16 || !packed || (!out32 && !out16)) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || h < 1 || w < 1 || act < 0 || act > 2) return fail(CAE_ERR_ARG, "bad shape or activation");
+    GGArgs a{};
+    a.in = x16;
+    a.out32 = out32;
+    a.out16 = out16;
+    a.wp = packed;
+    a.bias = bias;
+    a.N = n;
+    a.IH = h;
+    a.IW = w;
+    a.Ck = ck;
+    a.Cn = cn;
+    a.OH = h;
+    a.OW = w;
+    a.LH = h;
+    a.LW = w;
+    a.S = 1;
+    a.SO = 1;
+    a.reflect = 0;
+    a.act = act;
+    a.ktaps = 1;
+    a.ntaps = 1;
+    a.dy[0] = a.dx[0] = a.wt[0] = 0;
+    return launch_gg(a, (hipStream_t)stream);
+}
+
+int cae_t_wgrad_pointwise(const void *x16, const void *y16, int n, int h, int w, int ca, int cb, float *gw32, void *stream) {
+    if (n < 1 || h < 1 || w < 1) return fail(CAE_ERR_ARG, "bad shape");
+    return wgrad_impl(x16, n, h, w, ca, y16, h, w, cb, 1, 0, 1, gw32, stream);
+}
+
+int cae_t_im2col_s2(const float *x_nchw, int n, int c, int h, int w, int oh, int ow, int ks, int reflect, void *out16,
+                    void *stream) {
+    if (!x_nchw || !out16) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || c < 1 || h < 1 || w < 1 || oh < 1 || ow < 1 || (ks != 3 && ks != 5) || ks * ks * c > 32)
+        return fail(CAE_ERR_ARG, "bad shape (kernel_size^2 * channels must fit 32)");
+    hipLaunchKernelGGL(im2col_s2_kernel, dim3(ew_grid((size_t)n * oh * ow * 32)), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                       (__bf16 *)out16, n, c, h, w, oh, ow, ks, reflect);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_t_col2im_s2(const float *u32, const float *bias, int n, int c, int h, int w, int ks, float *out_nchw, void *stream) {
+    if (!u32 || !out_nchw) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || c < 1 || h < 1 || w < 1 || (ks != 3 && ks != 5) || ks * ks * c > 32)
+        return fail(CAE_ERR_ARG, "bad shape (kernel_size^2 * channels must fit 32)");
+    hipLaunchKernelGGL(col2im_s2_kernel, dim3(ew_grid((size_t)n * c * 4 * h * w)), dim3(256), 0, (hipStream_t)stream, u32, bias,
+                       out_nchw, n, c, h, w, ks);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
 int cae_t_act_backward(const void *g16, float *gext32, int pad, const void *y16, int n, int h, int w, int cp, int act,
                        void *out16, void *stream) {
     if ((!g16 && !gext32) || !y16 || !out16) return fail(CAE_ERR_ARG, "NULL argument");
@@ -418,9 +476,6 @@ int cae_t_deconv_dgrad(const void *gz16, int n, int h, int w, int cout_p, const 
     return strided_corr(gz16, n, 2 * h, 2 * w, cout_p, packed, ks, 0, gx32, gx16, cin_p, h, w, nullptr, (hipStream_t)stream);
 }
 
-static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const void *ysmall16, int oh, int ow, int cb, int ks,
-                      int reflect, int S, float *gw32, void *stream);
-
 int cae_t_wgrad(const void *xbig16, int n, int h, int w, int ca, const void *ysmall16, int oh, int ow, int cb, int ks,
                 int reflect, float *gw32, void *stream) {
     if (n < 1 || oh < 1 || ow < 1 || 2 * oh < h || 2 * ow < w) return fail(CAE_ERR_ARG, "bad shape");
@@ -436,7 +491,7 @@ int cae_t_wgrad_s1(const void *x16, int n, int h, int w, int ca, const void *y16
 static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const void *ysmall16, int oh, int ow, int cb, int ks,
                       int reflect, int S, float *gw32, void *stream) {
     if (!xbig16 || !ysmall16 || !gw32) return fail(CAE_ERR_ARG, "NULL argument");
-    if (ks != 3 && ks != 5) return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+    if (ks != 1 && ks != 3 && ks != 5) return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (1, 3 or 5)", ks);
     if (bad_channels(ca) || bad_channels(cb)) return fail(CAE_ERR_ARG, "channel counts must be multiples of 32, at most 192");
     hipStream_t st = (hipStream_t)stream;
     WGArgs a{};

@@ -727,6 +727,68 @@ __global__ void __launch_bounds__(CT * 64, 1) gdn_gemm_b_kernel(const float *gn,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Edge layers (3 image channels): the first analysis layer and the last synthesis layer as POINTWISE GEMMs over
+// K = (tap, channel) <= 32 instead of 32-channel padding of a 3-channel tensor (ten times the useful work, and a
+// 32-channel copy of the image): im2col of the module-boundary NCHW tensor straight into [N][OH][OW][32] bf16
+// (j = tap * C + c; reflect padding: the first conv's input; zeros: the last layer's output gradient), a 1 x 1
+// gather-GEMM / weight gradient on it, and for the last layer's forward the transposed form: per INPUT position the 27
+// products u[pos][(tap, co)], then col2im sums the <= 4 terms of every output pixel into NCHW fp32.
+// ---------------------------------------------------------------------------------------------------------------
+static __global__ void im2col_s2_kernel(const float *x, __bf16 *out, int N, int C, int H, int W, int OH, int OW, int ks,
+                                        int reflect) {
+    const size_t total = (size_t)N * OH * OW * 32;
+    const int P = ks / 2, K = ks * ks * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 31);
+        size_t r = i >> 5;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int n = (int)(r / OH);
+        float v = 0.0f;
+        if (j < K) {
+            const int tap = j / C, c = j - tap * C;
+            int iy = 2 * oy + tap / ks - P, ix = 2 * ox + tap % ks - P;
+            bool ok = true;
+            if (reflect) {
+                iy = reflect_idx(iy, H);
+                ix = reflect_idx(ix, W);
+            } else {
+                ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            }
+            if (ok) v = x[((size_t)n * C + c) * H * W + (size_t)iy * W + ix];
+        }
+        out[i] = (__bf16)v;
+    }
+}
+
+// out[n][c][Y][X] = bias[c] + sum over taps (ky, kx) with (Y + P - ky), (X + P - kx) even and inside of
+// u[n][(Y + P - ky) / 2][(X + P - kx) / 2][(ky * ks + kx) * C + c]      (ConvTranspose2d(k, stride 2, padding k//2, output_padding 1))
+static __global__ void col2im_s2_kernel(const float *u, const float *bias, float *out, int N, int C, int H, int W, int ks) {
+    const int OH = 2 * H, OW = 2 * W, P = ks / 2;
+    const size_t total = (size_t)N * C * OH * OW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % OW);
+        size_t r = i / OW;
+        const int Y = (int)(r % OH);
+        r /= OH;
+        const int c = (int)(r % C);
+        const int n = (int)(r / C);
+        float s = bias ? bias[c] : 0.0f;
+        for (int ky = (Y + P) & 1; ky < ks; ky += 2) {
+            const int iy = (Y + P - ky) >> 1;
+            if (iy < 0 || iy >= H || Y + P - ky < 0) continue;
+            for (int kx = (X + P) & 1; kx < ks; kx += 2) {
+                const int ix = (X + P - kx) >> 1;
+                if (ix < 0 || ix >= W || X + P - kx < 0) continue;
+                s += u[(((size_t)n * H + iy) * W + ix) * 32 + (ky * ks + kx) * C + c];
+            }
+        }
+        out[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // layout conversions between the module boundary (NCHW fp32) and the T layout
 // ---------------------------------------------------------------------------------------------------------------
 static __global__ void nchw_to_t_kernel(const float *in, __bf16 *o16, float *o32, int N, int C, int H, int W, int Cp) {

@@ -110,6 +110,12 @@ def _bias_p(b: Optional[torch.Tensor], cp: int, dev) -> Optional[torch.Tensor]:
     return out
 
 
+def _edge_ok(spec: 'LayerSpec', c_img: int) -> bool:
+    """the 3-channel edge of a track as a pointwise GEMM over K = (tap, channel) <= 32 (cae_t_im2col_s2 / cae_t_col2im_s2):
+    no stride-1 pre-convolution at that edge, k^2 * channels fits one 32-deep chunk; CAE_EDGE_GEMM=0 keeps the padded form"""
+    return (not spec.has_pre and spec.ks * spec.ks * c_img <= 32 and os.environ.get('CAE_EDGE_GEMM', '1') != '0')
+
+
 def _act_backward(g16, gext32, pad, y16, act):
     """gradient through LeakyReLU / ReLU: g * (y > 0 ? 1 : slope), y = the activation's output; g bf16, or the fp32
     extended-domain gradient (folded in place first) -> bf16"""
@@ -223,12 +229,37 @@ class AnalysisFn(torch.autograd.Function):
         layers = _split_params(specs, tensors)
         n, _, h, w = x.shape
         dev = x.device
-        a16, _ = _from_nchw(x, specs[0].cin_p)
+        edge = _edge_ok(specs[0], specs[0].cin)
+        a16 = None if edge else _from_nchw(x, specs[0].cin_p)[0]
         saved, dims = [], []
         z32 = None
         for i, (s, (wt, b, beta, gamma, pw, pb)) in enumerate(zip(specs, layers)):
             last = i == len(specs) - 1
             oh, ow = (h + 1) // 2, (w + 1) // 2
+            if i == 0 and edge:
+                # first layer: K = (tap, channel) = 27 of 32 as ONE contraction chunk of a 1 x 1 GEMM on the im2col of the image
+                cols = torch.empty((n, oh, ow, 32), dtype=torch.bfloat16, device=dev)
+                xc = x.detach().float().contiguous()
+                _lib.check(L.cae_t_im2col_s2(xc.data_ptr(), n, s.cin, h, w, oh, ow, s.ks, 1, cols.data_ptr(), _st()))
+                w1 = torch.zeros((s.cout, 32, 1, 1), dtype=torch.float32, device=dev)
+                w1[:, :s.ks * s.ks * s.cin, 0, 0] = wt.detach().float().permute(0, 2, 3, 1).reshape(s.cout, -1)
+                wp = _pack(w1, 1, 1)
+                bias_p = _bias_p(b, s.cout_p, dev)
+                need32 = s.has_gdn or last
+                z32 = torch.empty((n, oh, ow, s.cout_p), dtype=torch.float32, device=dev) if need32 else None
+                z16 = None if need32 else torch.empty((n, oh, ow, s.cout_p), dtype=torch.bfloat16, device=dev)
+                _lib.check(L.cae_t_pointwise(cols.data_ptr(), n, oh, ow, 32, wp.data_ptr(), _ptr(z32), _ptr(z16), s.cout_p,
+                                             _ptr(bias_p), 0 if need32 else s.act, _st()))
+                f_saved = None
+                if s.has_gdn:
+                    a16, f_saved = _gdn_forward(z32, beta, gamma, False)
+                elif not last:
+                    a16 = z16
+                saved.append(dict(a_in=cols, p=None, z=z32 if s.has_gdn else None, f=f_saved,
+                                  out=a16 if (s.act and not need32) else None, edge=True))
+                dims.append((h, w, oh, ow))
+                h, w = oh, ow
+                continue
             a16_in, p16 = a16, None
             if s.has_pre:  # stride-1 reflect convolution cin -> cin + activation
                 p16 = torch.empty((n, h, w, s.cin_p), dtype=torch.bfloat16, device=dev)
@@ -276,6 +307,15 @@ class AnalysisFn(torch.autograd.Function):
             if sv['out'] is not None and not masked:  # through the unit's activation
                 g16 = _act_backward(g16, None, 0, sv['out'], s.act)
             masked = False
+            if sv.get('edge'):  # first layer as a pointwise GEMM: its weight gradient over the im2col, back in (cout, cin, k, k)
+                gw1 = torch.empty((1, 32, s.cout_p), dtype=torch.float32, device=dev)
+                _lib.check(L.cae_t_wgrad_pointwise(sv['a_in'].data_ptr(), g16.data_ptr(), n, oh, ow, 32, s.cout_p,
+                                                   gw1.data_ptr(), _st()))
+                per_layer[i][0] = (gw1[0, :kk * s.cin, :s.cout].t().reshape(s.cout, s.ks, s.ks, s.cin)
+                                   .permute(0, 3, 1, 2).contiguous())
+                if b is not None:
+                    per_layer[i][1] = _colsum(g16, s.cout)
+                break  # (the image itself needs no gradient)
             main_in = sv['p'] if s.has_pre else sv['a_in']
             gw = torch.empty((kk, s.cin_p, s.cout_p), dtype=torch.float32, device=dev)
             _lib.check(L.cae_t_wgrad(main_in.data_ptr(), n, h, w, s.cin_p, g16.data_ptr(), oh, ow, s.cout_p, s.ks, 1,
@@ -338,6 +378,25 @@ class SynthesisFn(torch.autograd.Function):
                 wpp, bpp = _pack(pw, 0, s.ks), _bias_p(pb, s.cin_p, dev)
                 _lib.check(L.cae_t_corr_s1(a16.data_ptr(), n, h, w, s.cin_p, wpp.data_ptr(), s.ks, 2, None, p16.data_ptr(),
                                            s.cin_p, _ptr(bpp), s.act, _st()))
+            if last and _edge_ok(s, s.cout):
+                # last layer: per INPUT position the k*k*cout <= 32 products with the weights (a 1 x 1 GEMM), then col2im
+                K = s.ks * s.ks * s.cout
+                w1 = torch.zeros((32, s.cin, 1, 1), dtype=torch.float32, device=dev)  # (j = tap * cout + co, ci)
+                w1[:K, :, 0, 0] = wt.detach().float().permute(2, 3, 1, 0).reshape(K, s.cin)
+                wp = _pack(w1, 1, 1)
+                main_in = p16 if p16 is not None else a16
+                u32 = torch.empty((n, h, w, 32), dtype=torch.float32, device=dev)
+                _lib.check(L.cae_t_pointwise(main_in.data_ptr(), n, h, w, s.cin_p, wp.data_ptr(), u32.data_ptr(), None, 32,
+                                             None, 0, _st()))
+                x_r = torch.empty((n, s.cout, 2 * h, 2 * w), dtype=torch.float32, device=dev)
+                bias_c = None if b is None else b.detach().float().contiguous()
+                _lib.check(L.cae_t_col2im_s2(u32.data_ptr(), _ptr(bias_c), n, s.cout, h, w, s.ks, x_r.data_ptr(), _st()))
+                saved.append(dict(a_in=a16_in, p=p16, z=None, f=None, out=None, edge=True))
+                dims.append((h, w))
+                ctx.specs, ctx.saved, ctx.dims = specs, saved, dims
+                ctx.layers = [tuple(t.detach() if t is not None else None for t in l) for l in layers]
+                ctx.need_input_grad = yq.requires_grad
+                return x_r
             wp = _pack(wt, 0, s.ks)
             bias_p = _bias_p(b, s.cout_p, dev)
             need32 = s.has_gdn or last
@@ -367,7 +426,8 @@ class SynthesisFn(torch.autograd.Function):
         specs, saved, dims, layers = ctx.specs, ctx.saved, ctx.dims, ctx.layers
         n = gx.shape[0]
         dev = gx.device
-        g16, _ = _from_nchw(gx, specs[-1].cout_p)  # gradient with respect to the last layer's output
+        edge = bool(saved[-1].get('edge'))
+        g16 = None if edge else _from_nchw(gx, specs[-1].cout_p)[0]  # gradient with respect to the last layer's output
         per_layer = [[None] * 6 for _ in specs]
         g_in = None
         masked = False  # g16 already went through this unit's activation (applied on the fp32 gradient: one rounding)
@@ -377,6 +437,45 @@ class SynthesisFn(torch.autograd.Function):
             sv = saved[i]
             h, w = dims[i]
             kk = s.ks * s.ks
+            if sv.get('edge'):
+                # last layer as a pointwise GEMM: gu[pos][(tap, co)] = g_x[2 pos - P + tap][co] (im2col of the output
+                # gradient, zeros outside); weight gradient and data gradient are 1 x 1 contractions with it
+                K = kk * s.cout
+                gxc = gx.detach().float().contiguous()
+                gu16 = torch.empty((n, h, w, 32), dtype=torch.bfloat16, device=dev)
+                _lib.check(L.cae_t_im2col_s2(gxc.data_ptr(), n, s.cout, 2 * h, 2 * w, h, w, s.ks, 0, gu16.data_ptr(), _st()))
+                main_in = sv['p'] if s.has_pre else sv['a_in']
+                gw1 = torch.empty((1, s.cin_p, 32), dtype=torch.float32, device=dev)
+                _lib.check(L.cae_t_wgrad_pointwise(main_in.data_ptr(), gu16.data_ptr(), n, h, w, s.cin_p, 32, gw1.data_ptr(),
+                                                   _st()))
+                per_layer[i][0] = (gw1[0, :s.cin, :K].reshape(s.cin, s.ks, s.ks, s.cout).permute(0, 3, 1, 2).contiguous())
+                if b is not None:
+                    per_layer[i][1] = gxc.bfloat16().float().sum(dim=(0, 2, 3))
+                if i == 0 and not ctx.need_input_grad:
+                    break
+                w1d = torch.zeros((s.cin, 32, 1, 1), dtype=torch.float32, device=dev)  # (ci, j)
+                w1d[:, :K, 0, 0] = wt.detach().float().permute(0, 2, 3, 1).reshape(s.cin, K)
+                wp_d = _pack(w1d, 1, 1)
+                prev_gdn = i > 0 and specs[i - 1].has_gdn
+                prev_act = i > 0 and saved[i - 1]['out'] is not None
+                want32 = prev_gdn or prev_act or i == 0
+                gx32 = torch.empty((n, h, w, s.cin_p), dtype=torch.float32, device=dev) if want32 else None
+                gx16 = None if want32 else torch.empty((n, h, w, s.cin_p), dtype=torch.bfloat16, device=dev)
+                _lib.check(L.cae_t_pointwise(gu16.data_ptr(), n, h, w, 32, wp_d.data_ptr(), _ptr(gx32), _ptr(gx16), s.cin_p,
+                                             None, 0, _st()))
+                if i == 0:
+                    g_in = _to_nchw(gx32, s.cin)
+                elif prev_gdn:
+                    z_prev, f_prev = saved[i - 1]['z'], saved[i - 1]['f']
+                    _, _, beta_p, gamma_p, _, _ = layers[i - 1]
+                    g16, g_beta, g_gamma = _gdn_backward(z_prev, gx32, 0, beta_p, gamma_p, True, f_prev)
+                    per_layer[i - 1][2], per_layer[i - 1][3] = g_beta, g_gamma
+                elif prev_act:
+                    g16 = _act_backward(None, gx32, 0, saved[i - 1]['out'], specs[i - 1].act)
+                    masked = True
+                else:
+                    g16 = gx16
+                continue
             if sv['out'] is not None and not masked:  # through the unit's activation
                 g16 = _act_backward(g16, None, 0, sv['out'], s.act)
             masked = False

@@ -303,6 +303,19 @@ int cae_t_wgrad_s1(const void *x16, int n, int h, int w, int ca, const void *y16
 int cae_t_act_backward(const void *g16, float *gext32, int pad, const void *y16, int n, int h, int w, int cp, int act,
                        void *out16, void *stream);
 
+/* Edge layers with <= 3 image channels as pointwise GEMMs over K = (tap, channel) <= 32 (instead of padding 3 channels to
+ * 32): cae_t_im2col_s2 gathers the stride-2 taps of an NCHW fp32 tensor into [n][oh][ow][32] bf16 (j = tap * c + channel;
+ * reflect = 1: the first analysis layer's input (nn.Conv2d reflect, _autoencoders.py:78-85); 0: zeros outside -- the last
+ * synthesis layer's output gradient, oh = h / 2); cae_t_pointwise / cae_t_wgrad_pointwise are the 1 x 1 gather-GEMM and
+ * its weight gradient on channels-last bf16 tensors; cae_t_col2im_s2 sums the <= 4 products u[pos][(tap, channel)] of every
+ * output pixel of ConvTranspose2d(k, 2, k//2, output_padding 1) (:204-211) into NCHW fp32 (+ bias). */
+int cae_t_im2col_s2(const float *x_nchw, int n, int c, int h, int w, int oh, int ow, int ks, int reflect, void *out16,
+                    void *stream);
+int cae_t_col2im_s2(const float *u32, const float *bias, int n, int c, int h, int w, int ks, float *out_nchw, void *stream);
+int cae_t_pointwise(const void *x16, int n, int h, int w, int ck, const void *packed, float *out32, void *out16, int cn,
+                    const float *bias, int act, void *stream);
+int cae_t_wgrad_pointwise(const void *x16, const void *y16, int n, int h, int w, int ca, int cb, float *gw32, void *stream);
+
 /* Fused forms (csrc/cae_train_gdn.hpp; cp <= 128): the forward also saves the per-element factor f (y = z f: n^(-1/2),
  * IGDN n^(1/2)) in the register order the backward reads back -- f_saved holds cae_t_gdn_saved_elems(pixels, cp) floats
  * (0: shape not built) -- and the backward is ONE kernel: g_z (bf16), g_gamma, g_beta from z, f and the gradient with
