@@ -528,6 +528,7 @@ def main():
                             'frac = that time / measured step time',
                 'batch16': train_run(cae, cfg, state, 16, 256, 20, 3),
                 'batch128': train_run(cae, cfg, state, 128, 256, 8, 2),
+                'batch256': train_run(cae, cfg, state, 256, 256, 5, 2),
             }
         print(json.dumps(line))
     if world > 1:

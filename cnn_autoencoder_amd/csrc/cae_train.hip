@@ -81,6 +81,8 @@ int launch_gg(GGArgs &a, hipStream_t st) {
             break;
         }
     }
+    a.m_plane = (unsigned)(((1ull << 32) + (unsigned)(a.HR * a.HC) - 1) / (unsigned)(a.HR * a.HC));
+    a.m_hc = (unsigned)(((1ull << 32) + (unsigned)a.HC - 1) / (unsigned)a.HC);
     a.tiles_x = (a.LW + 15) / 16;
     a.tiles_y = (a.LH + 15) / 16;
     a.zero = zero_page();
@@ -442,7 +444,7 @@ int cae_t_act_backward(const void *g16, float *gext32, int pad, const void *y16,
     if (n < 1 || h < 1 || w < 1 || pad < 0 || cp % 32 || act < 1 || act > 2) return fail(CAE_ERR_ARG, "bad shape or activation");
     hipStream_t st = (hipStream_t)stream;
     if (!g16 && pad > 0) {  // reflect fold of the extended-domain gradient, in place
-        hipLaunchKernelGGL(fold_inplace_kernel, dim3((unsigned)(n * h)), dim3(256), 0, st, gext32, h, w, pad, cp);
+        hipLaunchKernelGGL(fold_inplace_kernel, dim3((unsigned)(n * (2 * pad + 1))), dim3(256), 0, st, gext32, h, w, pad, cp);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid((size_t)n * h * w * cp)), dim3(256), 0, st, (const __bf16 *)g16,
@@ -520,6 +522,8 @@ static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const voi
     a.dxmin = -P;
     a.HR = S * 7 + ks;
     a.HC = S * 15 + ks;
+    a.m_hc = (unsigned)(((1ull << 32) + (unsigned)a.HC - 1) / (unsigned)a.HC);
+    a.m_ypp = (unsigned)(((1ull << 32) + (unsigned)(cb / 8) - 1) / (unsigned)(cb / 8));
     a.tiles_x = (ow + 15) / 16;
     a.tiles_y = (oh + 7) / 8;
     a.total_tiles = n * a.tiles_x * a.tiles_y;
@@ -626,7 +630,7 @@ int cae_t_gdn_backward_fused(const float *z32, const float *f_saved, float *gext
     HIP_TRY(hipMemsetAsync(ggamma, 0, (size_t)cp * cp * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(gbeta, 0, (size_t)cp * sizeof(float), st));
     if (pad > 0) {  // reflect fold of the extended-domain gradient, in place (touches the border pixels only)
-        hipLaunchKernelGGL(fold_inplace_kernel, dim3((unsigned)(n * h)), dim3(256), 0, st, gext32, h, w, pad, cp);
+        hipLaunchKernelGGL(fold_inplace_kernel, dim3((unsigned)(n * (2 * pad + 1))), dim3(256), 0, st, gext32, h, w, pad, cp);
         HIP_TRY(hipGetLastError());
     }
     GdnFusedArgs a{};

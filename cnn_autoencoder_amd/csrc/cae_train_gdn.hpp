@@ -56,16 +56,32 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // per (sample, row); lanes over channels.  Afterwards the interior of g is the gradient with respect to the unpadded
 // tensor and consumers read it with a plain offset.
 static __global__ void fold_inplace_kernel(float *g, int H, int W, int P, int C) {
-    const int n = blockIdx.x / H, y = blockIdx.x - n * H;
+    // jobs per sample: one block per fold ROW (rows 1..P and H-1-P..H-2: every column), plus one block for the fold
+    // COLUMNS of all other rows -- a block per (sample, row) spent its time being launched (16 384 blocks for 2 % of the pixels)
+    const int jobs = 2 * P + 1;
+    const int n = blockIdx.x / jobs, job = blockIdx.x - n * jobs;
     const int HP = H + 2 * P, WP = W + 2 * P;
-    const bool row_folds = (y >= 1 && y <= P) || (y <= H - 2 && y >= H - 1 - P);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const FoldSrc f{g, H, W, P};
-    for (int x = wave; x < W; x += nw) {
-        const bool col_folds = (x >= 1 && x <= P) || (x <= W - 2 && x >= W - 1 - P);
-        if (!row_folds && !col_folds) continue;
+    auto row_folds = [&](int y) { return (y >= 1 && y <= P) || (y <= H - 2 && y >= H - 1 - P); };
+    auto col_folds = [&](int x) { return (x >= 1 && x <= P) || (x <= W - 2 && x >= W - 1 - P); };
+    auto fix = [&](int y, int x) {
         float *dst = g + (((size_t)n * HP + y + P) * WP + x + P) * C;
         for (int c = lane; c < C; c += 64) dst[c] = fold_read(f, n, y, x, C, c);
+    };
+    if (job < 2 * P) {
+        const int y = job < P ? 1 + job : H - 1 - P + (job - P);
+        if (y < 0 || y >= H || !row_folds(y) || (job >= P && y <= P)) return;  // (tiny images: the two bands overlap)
+        for (int x = wave; x < W; x += nw) fix(y, x);
+    } else {
+        for (int y = wave; y < H; y += nw) {
+            if (row_folds(y)) continue;  // done by its row block
+            for (int k = 0; k < 2 * P; ++k) {
+                const int x = k < P ? 1 + k : W - 1 - P + (k - P);
+                if (x < 0 || x >= W || !col_folds(x) || (k >= P && x <= P)) continue;
+                fix(y, x);
+            }
+        }
     }
 }
 

@@ -78,6 +78,7 @@ struct GGArgs {
     int ntaps, ktaps;   // taps of this launch, taps of the packed weights (KS * KS)
     int dymin, dxmin, HR, HC;
     int taps_per_stage;
+    unsigned m_plane, m_hc;  // ceil(2^32 / (HR * HC)), ceil(2^32 / HC): exact quotients of piece indices by __umulhi
     int nq;             // pipelined form: 8-channel quarters of the contraction per staged slice (4 = a chunk, 2 = half), else 0
     int tiles_x, tiles_y;
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
@@ -111,9 +112,10 @@ __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
     for (int i = 0; i < MAXP; ++i) {
         int pc = (wave + i * 4) * 64 + lane;
         pc = pc < npieces ? pc : npieces - 1;
-        const int quarter = pc / plane;
+        // (a block lives for one tile: twenty pairs of integer divisions by run-time values here were a quarter of its time)
+        const int quarter = (int)__umulhi((unsigned)pc, p.m_plane);
         const int rem = pc - quarter * plane;
-        const int r = rem / p.HC, c = rem - r * p.HC;
+        const int r = (int)__umulhi((unsigned)rem, p.m_hc), c = rem - r * p.HC;
         int iy = p.S * i0 + p.dymin + r, ix = p.S * j0 + p.dxmin + c;
         bool ok = true;
         if (p.reflect) {
@@ -155,8 +157,8 @@ __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
         for (int i = 0; i < MAXW; ++i) {
             int f = wave + 4 * i;
             f = f < w_instr ? f : w_instr - 1;
-            const int tl = f / (NT * ksteps), rest = f - tl * (NT * ksteps);
-            const int nt = rest / ksteps, s = rest - nt * ksteps;
+            const int tl = ksteps == 2 ? f / (NT * 2) : f / NT, rest = f - tl * (NT * ksteps);  // (compile-time divisors)
+            const int nt = ksteps == 2 ? rest >> 1 : rest, s = rest - nt * ksteps;
             woff[i] = (unsigned)(((p.wt[tl] * (NT * 2) + nt * 2 + s) * 1024) + lane * 16);
         }
         const unsigned chunk_bytes = (unsigned)p.ktaps * (NT * 2) * 1024;
@@ -290,6 +292,7 @@ struct WGArgs {
     const void *zero;
     int N, H, W, Ca, OH, OW, Cb;
     int reflect;       // padding of X: 1 reflect, 0 zeros
+    unsigned m_hc, m_ypp;  // ceil(2^32 / HC), ceil(2^32 / (Cb / 8))
     int S;             // X is sampled at S * position + tap offset: 2 (the strided layers) or 1 (the stride-1 pre-convolutions)
     int kk;            // taps of the layer
     int dymin, dxmin, HR, HC;
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WGArgs p) {
             int pc = j * 64 + lane;
             pc = pc < x_pieces ? pc : x_pieces - 1;
             const int pix = pc >> 2, quarter = pc & 3;
-            const int r = pix / p.HC, c = pix - r * p.HC;
+            const int r = (int)__umulhi((unsigned)pix, p.m_hc), c = pix - r * p.HC;
             int iy = p.S * i0 + p.dymin + r, ix = p.S * j0 + p.dxmin + c;
             bool ok = true;
             if (p.reflect) {
@@ -357,7 +360,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WGArgs p) {
         for (int j = wave; j < y_instr; j += 4) {
             int pc = j * 64 + lane;
             pc = pc < y_pieces ? pc : y_pieces - 1;
-            const int pos = pc / ypp, part = pc - pos * ypp;
+            const int pos = (int)__umulhi((unsigned)pc, p.m_ypp), part = pc - pos * ypp;
             const int i = i0 + (pos >> 4), jj = j0 + (pos & 15);
             const bool ok = i < p.OH && jj < p.OW;  // positions outside contribute zero
             const void *src = ok ? (const void *)(y_n + (((size_t)i * p.OW + jj) * p.Cb) * 2 + part * 16) : p.zero;
