@@ -277,7 +277,7 @@ int launch_gdn_b_t(const float *gn, const float *z, long pixels, float *gg, floa
 template <int CT>
 int launch_gdn_fused_t(const GdnFusedArgs &a, bool backward, hipStream_t st) {
     constexpr int C = CT * 32;
-    constexpr int LDS_F = C * (C + 4) * 4 + 2 * 64 * C * 4 + 64 * (C * 2 + 16);
+    constexpr int LDS_F = 2 * 32 * C * 4 + 32 * (C * 2 + 16);  // (Gamma in registers)
     constexpr int LDS_B = C * (C + 4) * 4 + 4 * 32 * C * 4 + 32 * (C * 2 + 16);
     auto kf = gdn_fwd_fused_kernel<CT>;
     auto kb = gdn_bwd_fused_kernel<CT>;
@@ -287,8 +287,9 @@ int launch_gdn_fused_t(const GdnFusedArgs &a, bool backward, hipStream_t st) {
         HIP_TRY(hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         done = true;
     }
-    const long tiles = (a.pixels + (backward ? 31 : 63)) / (backward ? 32 : 64);
-    const unsigned grid = (unsigned)std::min<long>(tiles, 256);  // persistent: one block per CU walks the tiles
+    const long tiles = (a.pixels + 31) / 32;
+    // persistent blocks walk the tiles: one per CU (backward: Gamma + two tile sets fill the LDS), two per CU (forward)
+    const unsigned grid = (unsigned)std::min<long>(tiles, backward ? 256 : 512);
     if (backward)
         hipLaunchKernelGGL(kb, dim3(grid), dim3(CT * 64), LDS_B, st, a);
     else

@@ -127,20 +127,25 @@ __device__ __forceinline__ void gdn_load_gamma(float *mlds, const float *gamma, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// forward: 64-pixel tiles (two 32-pixel MFMA column tiles per wave)
+// forward: 32-pixel tiles
 // ---------------------------------------------------------------------------------------------------------------
+// Gamma lives in REGISTERS here: the A operand of a wave is its 32 rows of Gamma, i.e. C / 8 x 16 bytes per lane = 64 VGPRs
+// for 128 channels, loaded once per block.  Without the 66-KiB LDS image two blocks share a CU (32-pixel tiles: 41 KiB
+// each), so one block's element-wise / staging phases run under the other's MFMAs (one block per CU with Gamma in the
+// LDS and 64-pixel tiles: 0.47-0.55 of the fp32 MFMA peak; profiles/r03_experiments.md).
 template <int CT>
-__global__ void __launch_bounds__(CT * 64, 1) gdn_fwd_fused_kernel(const GdnFusedArgs p) {
+__global__ void __launch_bounds__(CT * 64, 2) gdn_fwd_fused_kernel(const GdnFusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int C = CT * 32, LD = C + 4, PT = 64;
-    constexpr int M_BYTES = C * LD * 4, Z_BYTES = PT * C * 4, YS = C * 2 + 16;  // padded bf16 output rows
-    float *mlds = (float *)smem;
-    char *zbuf = smem + M_BYTES;            // 2 x Z_BYTES
+    constexpr int C = CT * 32, PT = 32;
+    constexpr int Z_BYTES = PT * C * 4, YS = C * 2 + 16;  // padded bf16 output rows
+    char *zbuf = smem;                      // 2 x Z_BYTES
     char *ybuf = zbuf + 2 * Z_BYTES;        // PT x YS
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, m = lane & 31;
-    gdn_load_gamma<C>(mlds, p.gamma, threadIdx.x, CT * 64);
+    f32x4 gam[C / 8];  // Gamma[32 wave + m][8 q + 4 h .. + 3]
+#pragma unroll
+    for (int q = 0; q < C / 8; ++q) gam[q] = *(const f32x4 *)(p.gamma + (size_t)(32 * wave + m) * C + 8 * q + 4 * h);
     const long tiles = (p.pixels + PT - 1) / PT;
     auto zrow = [&](long gp) { return (const char *)(p.z + gp * C); };
     // The previous tile's outputs leave at the TOP of an iteration, before the next prefetch is issued: vmcnt counts loads
@@ -154,14 +159,11 @@ __global__ void __launch_bounds__(CT * 64, 1) gdn_fwd_fused_kernel(const GdnFuse
                 *(f32x4 *)((char *)p.y16 + (gp * C) * 2 + part * 16) = *(const f32x4 *)(ybuf + px * YS + part * 16);
         }
     };
-    f32x4 fkeep[2][4];  // the factors of the previous tile, stored one iteration later for the same reason
+    f32x4 fkeep[4];  // the factors of the previous tile, stored one iteration later for the same reason
     auto store_f = [&](long t) {
-        static_for<2>([&](auto pt_tag) {
-            constexpr int pt = decltype(pt_tag)::value;
-            static_for<4>([&](auto g_tag) {
-                constexpr int g = decltype(g_tag)::value;
-                *(f32x4 *)(p.f + ((((t * 2 + pt) * CT + wave) * 4 + g) * 64 + lane) * 4) = fkeep[pt][g];
-            });
+        static_for<4>([&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            *(f32x4 *)(p.f + (((t * CT + wave) * 4 + g) * 64 + lane) * 4) = fkeep[g];
         });
     };
     float bet[16];
@@ -179,51 +181,44 @@ __global__ void __launch_bounds__(CT * 64, 1) gdn_fwd_fused_kernel(const GdnFuse
         }
         if (tile + gridDim.x < tiles)
             gdn_stage<C, PT, CT>(zbuf + ((it + 1) & 1) * Z_BYTES, wave, lane, (tile + gridDim.x) * PT, p.pixels, zrow);
-        f32x16 acc[2];
+        f32x16 acc, acc1;  // two chains (even / odd k-steps)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            acc[0][r] = bet[r];
-            acc[1][r] = bet[r];
+            acc[r] = bet[r];
+            acc1[r] = 0.0f;
         }
-        // n[c][pix] = beta[c] + sum_j Gamma[c][j] z[pix][j]^2 :  A = Gamma rows of this wave's tile, B = z^2 (lane = pixel);
-        // the operands of step q + 1 are read while the MFMAs of step q run
+        // n[c][pix] = beta[c] + sum_j Gamma[c][j] z[pix][j]^2 :  A = Gamma rows of this wave's tile (registers), B = z^2
+        // (lane = pixel); the z pieces of step q + 1 are read while the MFMAs of step q run
         {
-            f32x4 mf[2], v0[2], v1[2];
-            auto fetch = [&](int q, int k) {
-                mf[k] = *(const f32x4 *)(mlds + (32 * wave + m) * LD + 8 * q + 4 * h);
-                v0[k] = *(const f32x4 *)(cur + gdn_slot<C>(m, 2 * q + h));
-                v1[k] = *(const f32x4 *)(cur + gdn_slot<C>(32 + m, 2 * q + h));
-            };
-            fetch(0, 0);
+            f32x4 v[2];
+            v[0] = *(const f32x4 *)(cur + gdn_slot<C>(m, h));
             static_for<C / 8>([&](auto q_tag) {
                 constexpr int q = decltype(q_tag)::value, k = q & 1;
-                if (q + 1 < C / 8) fetch(q + 1, k ^ 1);
-                v0[k] *= v0[k];
-                v1[k] *= v1[k];
+                if (q + 1 < C / 8) v[k ^ 1] = *(const f32x4 *)(cur + gdn_slot<C>(m, 2 * (q + 1) + h));
+                v[k] *= v[k];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[k][s], v0[k][s], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[k][s], v1[k][s], acc[1], 0, 0, 0);
+                for (int s = 0; s < 4; s += 2) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gam[q][s], v[k][s], acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gam[q][s + 1], v[k][s + 1], acc1, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
         }
         lds_barrier();  // the copy-out of the previous tile has read the output image (no wait for the prefetch)
-        // element-wise on the wave's own channels: run g = channels 32 wave + 8 g + 4 h .. + 3 of pixel 32 pt + m
-        static_for<2>([&](auto pt_tag) {
-            constexpr int pt = decltype(pt_tag)::value;
-            static_for<4>([&](auto g_tag) {
-                constexpr int g = decltype(g_tag)::value;
-                const f32x4 zz = *(const f32x4 *)(cur + gdn_slot<C>(32 * pt + m, 8 * wave + 2 * g + h));
-                bf16x4 y;
+        // element-wise on the wave's own channels: run g = channels 32 wave + 8 g + 4 h .. + 3 of pixel m
+        static_for<4>([&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            const f32x4 zz = *(const f32x4 *)(cur + gdn_slot<C>(m, 8 * wave + 2 * g + h));
+            bf16x4 y;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float d = acc[pt][4 * g + k];
-                    fkeep[pt][g][k] = p.inverse ? __builtin_amdgcn_sqrtf(d) : __builtin_amdgcn_rsqf(d);
-                    y[k] = (__bf16)(zz[k] * fkeep[pt][g][k]);
-                }
-                *(bf16x4 *)(ybuf + (32 * pt + m) * YS + (32 * wave + 8 * g + 4 * h) * 2) = y;
-            });
+            for (int k = 0; k < 4; ++k) {
+                const float d = acc[4 * g + k];
+                fkeep[g][k] = p.inverse ? __builtin_amdgcn_sqrtf(d) : __builtin_amdgcn_rsqf(d);
+                y[k] = (__bf16)(zz[k] * fkeep[g][k]);
+            }
+            *(bf16x4 *)(ybuf + m * YS + (32 * wave + 8 * g + 4 * h) * 2) = y;
         });
     }
     __syncthreads();
