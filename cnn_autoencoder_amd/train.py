@@ -692,11 +692,15 @@ def train_step(x: torch.Tensor, model, criterion, optimizers, forward_func=None,
 
 class GradReducer:
     """Data-parallel gradient averaging, one process per GPU (replaces nn.DataParallel's reduce-add to device 0,
-    _autoencoders.py:517): the gradients of all parameters are packed into a few flat fp32 buckets and all-reduced
-    (RCCL over xGMI on GPUs, gloo in the CPU tests), then averaged and scattered back.  The model holds about
-    2 M parameters (8 MB), so one or two buckets per step: latency-bound, a single ring is enough."""
+    _autoencoders.py:517): the gradients are packed into a few flat fp32 buckets and all-reduced (RCCL over xGMI on GPUs,
+    gloo in the CPU tests), averaged, and handed back as views of the bucket.  OVERLAPPED with the backward pass: a
+    post-accumulate hook per parameter counts a bucket down and launches its all-reduce (async) the moment its last
+    gradient exists -- the backward runs decoder, entropy model, encoder, so the decoder's bucket is on the wire while the
+    encoder's gradients are still being computed; ``reduce()`` (between ``backward()`` and the optimiser step) launches
+    what is left (parameters without a gradient count as zero), waits and averages.  The buckets are persistent: no
+    per-step concatenation.  The model holds about 2 M parameters (8 MB): latency-bound, a single ring."""
 
-    def __init__(self, params: Sequence[torch.Tensor], bucket_bytes: int = 16 << 20):
+    def __init__(self, params: Sequence[torch.Tensor], bucket_bytes: int = 2 << 20, overlap: bool = True):
         self.params = [p for p in params if p.requires_grad]
         self.buckets: List[List[torch.Tensor]] = [[]]
         size = 0
@@ -707,27 +711,63 @@ class GradReducer:
                 size = 0
             self.buckets[-1].append(p)
             size += nbytes
+        self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._views: List[Optional[List[torch.Tensor]]] = [None] * len(self.buckets)
+        self._works: List = [None] * len(self.buckets)
+        self._pending = [len(b) for b in self.buckets]
+        self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self.launched_in_backward = 0  # (statistics: buckets whose all-reduce started from a hook)
+        self._hooks = []
+        if overlap and hasattr(torch.Tensor, 'register_post_accumulate_grad_hook'):
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    @staticmethod
+    def _active() -> bool:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _on_grad(self, p):
+        if not self._active():
+            return
+        i = self._bucket_of[id(p)]
+        self._pending[i] -= 1
+        if self._pending[i] == 0 and self._works[i] is None:
+            self._launch(i)
+            self.launched_in_backward += 1
+
+    @torch.no_grad()
+    def _launch(self, i: int):
+        import torch.distributed as dist
+        bucket = self.buckets[i]
+        if self._flat[i] is None or self._flat[i].device != bucket[0].device:
+            self._flat[i] = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=bucket[0].device)
+            views, off = [], 0
+            for p in bucket:
+                views.append(self._flat[i][off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self._views[i] = views
+        have = [(v, p.grad) for v, p in zip(self._views[i], bucket) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        for v, p in zip(self._views[i], bucket):
+            if p.grad is None:
+                v.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g.to(torch.float32) for _, g in have])
+        self._works[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, async_op=True)
 
     @torch.no_grad()
     def reduce(self):
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self._active():
             return
         world = dist.get_world_size()
-        works = []
-        for bucket in self.buckets:
-            live = [p for p in bucket]
-            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in live])
-            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, live))
-        for work, flat, live in works:
-            work.wait()
-            flat.div_(world)
-            off = 0
-            for p in live:
-                n = p.numel()
-                g = flat[off:off + n].view_as(p).to(p.dtype)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-                off += n
+        for i in range(len(self.buckets)):
+            if self._works[i] is None:
+                self._launch(i)
+        for i, bucket in enumerate(self.buckets):
+            self._works[i].wait()
+            self._flat[i].div_(world)
+            for v, p in zip(self._views[i], bucket):
+                p.grad = v if p.dtype == torch.float32 else v.to(p.dtype)
+            self._works[i] = None
+            self._pending[i] = len(bucket)

@@ -153,6 +153,54 @@ def _grad_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _overlap_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from cnn_autoencoder_amd import train
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(),
+                              torch.nn.Linear(64, 3))
+    ref = [p.detach().clone() for p in net.parameters()]
+    reducer = train.GradReducer(list(net.parameters()), bucket_bytes=8192)  # several buckets
+    gen = torch.Generator().manual_seed(11)
+    out = []
+    for step in range(2):
+        x = torch.randn(8, 40, generator=gen)  # the global batch; this rank takes its half
+        lo = 4 * rank
+        net(x[lo:lo + 4]).pow(2).sum().backward()  # hooks fire here: buckets start their all-reduce during the backward
+        started = reducer.launched_in_backward
+        reducer.reduce()
+        full = torch.nn.Sequential(*[type(m)(m.in_features, m.out_features) if isinstance(m, torch.nn.Linear) else torch.nn.Tanh()
+                                     for m in net])
+        for q, r in zip(full.parameters(), ref):
+            q.data.copy_(r)
+        full(x).pow(2).sum().backward()
+        out.append(dict(started=started, got=[p.grad.clone() for p in net.parameters()],
+                        want=[0.5 * q.grad for q in full.parameters()]))
+        for p in net.parameters():
+            p.grad = None
+    torch.save(out, os.path.join(out_dir, f'o{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_starts_during_the_backward(tmp_path):
+    """GradReducer's hooks launch a bucket's all-reduce as soon as its last gradient exists (overlap with the rest of the
+    backward); the averaged gradients equal half the full-batch gradient; buckets persist over steps."""
+    world = 2
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(str(tmp_path / f'o{r}.pt'), weights_only=False) for r in range(world)]
+    for step in range(2):
+        assert outs[0][step]['started'] >= 2 * (step + 1)  # >= 2 of the buckets per step went out from a hook
+        for a, b, w in zip(outs[0][step]['got'], outs[1][step]['got'], outs[0][step]['want']):
+            assert torch.equal(a, b)
+            assert torch.allclose(a, w, rtol=1e-5, atol=1e-6)
+
+
 def test_two_ranks_average_their_gradients(tmp_path):
     """train.GradReducer (data-parallel gradient all-reduce replacing nn.DataParallel, _autoencoders.py:517): every
     rank ends with the mean gradient, over several buckets, missing gradients counted as zero."""
