@@ -27,6 +27,7 @@ Objects in the line besides the driver's contract:
   cpu_baseline  the CPU oracle (torch-CPU conv + restated GDN + C rANS) on a bounded sample of the
                 same tiles on this host's cores -- a reported baseline, not the target
   parity_vs_cpu the GPU path against that oracle on the very same tiles: bpp, PSNR, bitstreams, pixels
+  host_8cpu     (N=1) the same round trip in a child process restricted to 8 CPUs (--cpus 8): the host budget per GPU, measured
   low_rate_state (N=1) the same workload with a low-rate synthetic state (~0.9 bpp instead of 4): brackets the host coder's cost
   train         (N=1) BASELINE config 5: train.train_step on 256x256 patches, batch 16 and 128, against the mixed
                 bf16-conv / fp32-GDN roofline
@@ -349,10 +350,15 @@ def main():
     ap.add_argument('--precision', choices=['f16x3', 'fp32'], default='f16x3',
                     help='conv/GDN arithmetic: f16x3 = operands split into two f16 halves, 3 f16 MFMAs per product, '
                          'fp32 accumulate (fp32-class accuracy); fp32 = exact v_mfma_f32_32x32x2_f32')
+    ap.add_argument('--cpus', type=int, default=0,
+                    help='restrict this process to its first N allowed CPUs before anything starts (the host budget of a rank '
+                         'on a node with N cores per GPU)')
     ap.add_argument('--rehearse-on-one-gpu', action='store_true',
                     help='N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and the collective runs on gloo '
                          '(RCCL refuses two ranks on one device); numbers are meaningless, the code path is the real one')
     args = ap.parse_args()
+    if args.cpus > 0:
+        os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:args.cpus])
 
     import torch.distributed as dist
     import cnn_autoencoder_amd as cae
@@ -521,6 +527,19 @@ def main():
             # standing in for a trained model) on the same tiles
             low = synth.synthetic_state(cfg, seed=0, **synth.LOW_RATE)
             line['low_rate_state'] = sub_run(cae, slide, cfg, low, args.precision, H, tiles_dev, 16, 2, dist, fit=True)
+            # the same round trip with 8 CPUs for this rank (what a node with 8 cores per GPU gives): a child process with its
+            # affinity cut to 8 CPUs; the coder pools and the lockstep width follow cae_cpu_budget()
+            try:
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpus', '8', '--steps', '32', '--warmup', '2',
+                                    '--no-sub-runs', '--no-cpu-baseline', '--precision', args.precision],
+                                   capture_output=True, text=True, timeout=300)
+                sub = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+                line['host_8cpu'] = dict(tiles_per_s=sub['value'], ms_per_step=sub['ms_per_step'], host_use=sub['host_use'],
+                                         host_coder_threads=sub['host_coder_threads'], host_ms_per_step=sub['host_ms_per_step'],
+                                         vs_unrestricted=sub['value'] / line['value'])
+            except Exception as e:  # noqa: BLE001 - a side measurement must not cost the line
+                line['host_8cpu'] = dict(error=repr(e)[:200])
             # BASELINE config 5 (train_cae_ms.py rate-distortion loop): canonical model, 256x256 patches
             line['train'] = {
                 'dtype': 'bf16 convolutions (fp32 accumulate), fp32 GDN / IGDN (v_mfma_f32_32x32x2_f32), fp32 optimiser',

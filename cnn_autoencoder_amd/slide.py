@@ -120,9 +120,11 @@ class SlideCoder:
         # core), so the decode pool gets one thread per work item and the encode pool half as many; 24 runnable
         # threads on 16 CPUs caused no cgroup throttling (about 11 CPUs busy on average), while pools of 5 + 8 left
         # the GPU waiting for the host.
+        # Below 12 CPUs (tools/sweep_host_budget.sh, 8 CPUs, lockstep 4: 8 + 8 threads 2352 tiles/s, 4 + 8 2133, 3 + 5 / 2 + 6
+        # 1800-2100): the host is the bottleneck anyway, so both pools may use every CPU -- whichever stage has work runs.
         budget = int(_lib.lib().cae_cpu_budget())
         dec = max(1, min(16, budget))
-        enc = max(1, min(16, budget // 2))
+        enc = max(1, min(16, budget if budget < 12 else budget // 2))
         return enc, dec
 
     # ---- simple (unpipelined) entry points ---------------------------------------------------
