@@ -302,19 +302,25 @@ int decode_streams(const EntropyTables &T, const uint8_t *const *bufs, const siz
                         val = (int32_t)get_bits(xx, r[k]);
                         nb += val;
                     }
-                    int32_t raw = 0;
+                    // a 32-bit escape value has at most 8 four-bit digits: a larger count can only come from a damaged
+                    // stream (and would shift by 32 or more below: found by UBSan, tests/test_sanitize.py)
+                    if (nb > 8) {
+                        r[k].bad = true;
+                        nb = 0;
+                    }
+                    uint32_t raw = 0;
                     for (int j = 0; j < nb && !r[k].bad; ++j) {
                         val = (int32_t)get_bits(xx, r[k]);
-                        raw |= (int32_t)((uint32_t)val << (j * kBypassBits));
+                        raw |= (uint32_t)val << (j * kBypassBits);
                     }
-                    v = raw >> 1;
+                    v = (int32_t)(raw >> 1);
                     if (raw & 1)
                         v = -v - 1;
                     else
-                        v += maxv;
+                        v = (int32_t)((uint32_t)v + (uint32_t)maxv);  // (wraps instead of overflowing on damaged input)
                 }
                 x[k] = xx;
-                s[k][i] = v + off;
+                s[k][i] = (int32_t)((uint32_t)v + (uint32_t)off);
             }
             bool bad = false;
             for (int k = 0; k < NS; ++k) bad |= r[k].bad;
