@@ -338,6 +338,7 @@ bool Model::f16_usable() const {
 static void free_stages(Layer &l) {
     for (auto &sg : l.stages) {
         if (sg.wp16) (void)hipFree(sg.wp16);
+        if (sg.gp16) (void)hipFree(sg.gp16);
         for (float *q : {sg.wp, sg.bias, sg.gp, sg.beta})
             if (q) (void)hipFree(q);
     }
@@ -356,6 +357,7 @@ Model::~Model() {
             free_stages(l);
             if (l.color_wp) (void)hipFree(l.color_wp);
             if (l.color_bias) (void)hipFree(l.color_bias);
+            if (l.color_wp16) (void)hipFree(l.color_wp16);
             if (l.wp16) (void)hipFree(l.wp16);
             if (l.gp16) (void)hipFree(l.gp16);
             if (l.wp_edge16) (void)hipFree(l.wp_edge16);
@@ -449,6 +451,11 @@ static int set_stage(Model *m, int track, Layer &l, int stage, const float *w, c
         if (!fits_f16(w, (size_t)l.cin * l.cin * m->ks * m->ks)) l.f16_bad = true;
         auto w16 = pack_weights_f16(w, tr, l.cin, l.cin, m->ks, ctin, tr);
         if ((rc = upload_raw(w16.data(), w16.size() * sizeof(_Float16), &sg.wp16))) return rc;
+        if (sg.gdn) {
+            if (!fits_f16(gamma, (size_t)l.cin * l.cin)) l.f16_bad = true;
+            auto g16 = pack_gamma_f16(gamma, l.cin, ctin);
+            if ((rc = upload_raw(g16.data(), g16.size() * sizeof(_Float16), &sg.gp16))) return rc;
+        }
     }
     if (track == CAE_ANALYSIS) {  // the fused first-layer kernels read the raw tile; a stage sits in between
         if (l.wp_edge) (void)hipFree(l.wp_edge);
@@ -468,8 +475,46 @@ static int pick_slot(int a, int b) {
     return 1;
 }
 
+// The split-f16 stride-1 kernel carries the (I)GDN / residual-sum epilogue up to 128 channels (registers); a wider unit
+// takes its stages on the fp32 kernels, between two layout conversions.
+static bool stages_need_fp32(const Layer &l) {
+    if (round_ct(l.cin) <= 4) return false;
+    for (const Layer::Stage &sg : l.stages)
+        if (sg.gdn || sg.add_res || sg.post_act) return true;
+    return false;
+}
+
+// f16: the split-f16 kernels (activation stages up to 192 channels; GDN / residual stages up to 128)
 static int run_stages(Model *m, const Layer &l, bool synthesis, int n, int ch, int cw, const float *&cur, int &cur_idx,
                       int &cur_planes, hipStream_t st, bool f16 = false, int *flag = nullptr) {
+    if (f16 && stages_need_fp32(l)) {
+        // split rows -> fp32 C8 (the unit input is dead afterwards), the stages on the fp32 kernels, fp32 C8 -> split rows
+        const int tmp = pick_slot(cur_idx, cur_idx);
+        const size_t rows = (size_t)n * cur_planes * ch;
+        if (synthesis)
+            hipLaunchKernelGGL(c8s_to_c8_kernel<true>, dim3(ew_grid(rows * cw)), dim3(256), 0, st, (const char *)cur,
+                               (float *)m->ws[tmp], rows, cw);
+        else
+            hipLaunchKernelGGL(c8s_to_c8_kernel<false>, dim3(ew_grid(rows * cw)), dim3(256), 0, st, (const char *)cur,
+                               (float *)m->ws[tmp], rows, cw);
+        HIP_TRY(hipGetLastError());
+        cur = (const float *)m->ws[tmp];
+        cur_idx = tmp;
+        int rc = run_stages(m, l, synthesis, n, ch, cw, cur, cur_idx, cur_planes, st, false, nullptr);
+        if (rc) return rc;
+        const int back = pick_slot(cur_idx, cur_idx);
+        const size_t orows = (size_t)n * cur_planes * ch;
+        if (synthesis)
+            hipLaunchKernelGGL(c8_to_c8s_kernel<true>, dim3(ew_grid(orows * cw)), dim3(256), 0, st, cur, (char *)m->ws[back],
+                               orows, cw, flag);
+        else
+            hipLaunchKernelGGL(c8_to_c8s_kernel<false>, dim3(ew_grid(orows * cw)), dim3(256), 0, st, cur, (char *)m->ws[back],
+                               orows, cw, flag);
+        HIP_TRY(hipGetLastError());
+        cur = (const float *)m->ws[back];
+        cur_idx = back;
+        return CAE_OK;
+    }
     const float *unit_in = cur;
     const int unit_idx = cur_idx, unit_planes = cur_planes;
     for (const Layer::Stage &sg : l.stages) {
@@ -501,14 +546,14 @@ static int run_stages(Model *m, const Layer &l, bool synthesis, int n, int ch, i
         b.res_planes = unit_planes;
         b.post_act = sg.post_act;
         int rc;
-        if (f16) {  // activation stage of a LeakyReLU / ReLU unit on the split-f16 kernels
-            if (sg.gdn || sg.add_res || sg.post_act || !sg.wp16)
-                return fail(CAE_ERR_UNSUPPORTED, "GDN / residual stride-1 stages run on the fp32 path: set precision 0");
+        if (f16) {
+            if (!sg.wp16 || (sg.gdn && !sg.gp16)) return fail(CAE_ERR_ARG, "stage uploaded before precision 1 was selected");
             b.wp = (const float *)sg.wp16;
+            b.gp = (const float *)sg.gp16;
             b.cci = (l.cin + 15) / 16;
             b.tiles_y = (ch + 15) / 16;
             b.flag = flag;
-            rc = launch_conv_s1_f16(m->ks, ctin, synthesis, b, st);
+            rc = launch_conv_s1_f16(m->ks, ctin, synthesis, sg.gdn, b, st);
         } else {
             rc = launch_conv_s1(m->ks, ctin, synthesis, sg.gdn, b, st);
         }
@@ -681,7 +726,6 @@ int cae_model_set_layer_stage(cae_model_t *mm, int track, int index, int stage, 
     if (act < 0 || act > 2 || post_act < 0 || post_act > 2) return fail(CAE_ERR_ARG, "bad activation");
     if ((beta == nullptr) != (gamma == nullptr)) return fail(CAE_ERR_ARG, "beta and gamma must come together");
     if (beta && act != 0) return fail(CAE_ERR_ARG, "a GDN stage has no other activation");
-    if (m->precision != 0) return fail(CAE_ERR_UNSUPPORTED, "stride-1 stages run on the fp32 path: set precision 0");
     std::lock_guard<std::mutex> lk(m->mu);
     Layer &l = (track == CAE_ANALYSIS ? m->enc : m->dec)[index];
     if (!l.set) return fail(CAE_ERR_ARG, "set the layer before its stages");
@@ -710,6 +754,15 @@ int cae_model_set_color_layer(cae_model_t *mm, int index, int cin, int cout, con
         l.color_bias = nullptr;
     }
     l.color_cout = cout;
+    if (l.color_wp16) {
+        (void)hipFree(l.color_wp16);
+        l.color_wp16 = nullptr;
+    }
+    if (m->precision == 1 && ct == 1) {  // f16x3: colour layers to at most 32 channels (wider: the fp32 path)
+        if (!fits_f16(w, (size_t)cin * cout * m->ks * m->ks)) l.f16_bad = true;
+        auto w16 = pack_weights_f16(w, false, cin, cout, m->ks, ct);
+        if ((rc = upload_raw(w16.data(), w16.size() * sizeof(_Float16), &l.color_wp16))) return rc;
+    }
     return CAE_OK;
 }
 
@@ -819,7 +872,8 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
     const bool u8_wide = f16 && !first_fused && fmt == CAE_FMT_U8_HWC;  // staged through fp32 C8 in ws[1]
     if (u8_wide) maxact = std::max(maxact, (size_t)n * p0 * h * w * 32);
     bool need_third_slot = false;  // two-stage residual units keep the unit input alive across both stages
-    for (auto &l : m->enc) need_third_slot |= l.stages.size() > 1 || (f16 && !conv_f16_fits(m->ks, l.ct, l.gdn));
+    for (auto &l : m->enc)
+        need_third_slot |= l.stages.size() > 1 || (f16 && (!conv_f16_fits(m->ks, l.ct, l.gdn) || stages_need_fp32(l)));
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
     if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
     if (maxact && need_third_slot && (rc = m->ensure_ws(3, maxact))) return rc;
@@ -833,7 +887,7 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
                 // rare (more than 4 input channels): uint8 -> fp32 C8 (exact /255) in ws[1] -> split rows in ws[0]
                 hipLaunchKernelGGL(u8hwc_to_c8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint8_t *)tiles,
                                    (float *)m->ws[1], n, h, w, m->c_org, p0);
-                hipLaunchKernelGGL(c8_to_c8s_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)m->ws[1],
+                hipLaunchKernelGGL(c8_to_c8s_kernel<false>, dim3(ew_grid(tot)), dim3(256), 0, st, (const float *)m->ws[1],
                                    (char *)m->ws[0], (size_t)n * p0 * h, w, flag);
             } else {
                 hipLaunchKernelGGL(nchw_to_c8s_kernel<false>, dim3(ew_grid(tot)), dim3(256), 0, st,
@@ -904,7 +958,7 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
             // this layer on the exact-fp32 kernel: split rows -> fp32 C8, convolution, (fp32 C8 -> split rows)
             const int tmp_in = pick_slot(cur_idx, out_idx);
             const size_t rows = (size_t)n * cur_planes * ch;
-            hipLaunchKernelGGL(c8s_to_c8_kernel, dim3(ew_grid(rows * cw)), dim3(256), 0, st, (const char *)cur,
+            hipLaunchKernelGGL(c8s_to_c8_kernel<false>, dim3(ew_grid(rows * cw)), dim3(256), 0, st, (const char *)cur,
                                (float *)m->ws[tmp_in], rows, cw);
             HIP_TRY(hipGetLastError());
             a.in = (const float *)m->ws[tmp_in];
@@ -913,7 +967,7 @@ static int analysis_impl(cae_model_t *mm, const void *tiles, int fmt, int n, int
             if ((rc = launch_conv(m->ks, l.ct, l.gdn, a, st))) return rc;
             if (!last) {
                 const size_t orows = (size_t)n * l.ct * 4 * a.OH;
-                hipLaunchKernelGGL(c8_to_c8s_kernel, dim3(ew_grid(orows * a.OW)), dim3(256), 0, st, (const float *)a.out,
+                hipLaunchKernelGGL(c8_to_c8s_kernel<false>, dim3(ew_grid(orows * a.OW)), dim3(256), 0, st, (const float *)a.out,
                                    (char *)final_out, orows, a.OW, flag);
                 HIP_TRY(hipGetLastError());
                 a.out = final_out;
@@ -989,7 +1043,7 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
         }
     }
     bool need_third_slot = false;
-    for (auto &l : m->dec) need_third_slot |= l.stages.size() > 1;
+    for (auto &l : m->dec) need_third_slot |= l.stages.size() > 1 || (f16 && stages_need_fp32(l));
     if ((rc = m->ensure_ws(0, in_bytes))) return rc;
     if (maxact && ((rc = m->ensure_ws(1, maxact)) || (rc = m->ensure_ws(2, maxact)))) return rc;
     if (maxact && need_third_slot && (rc = m->ensure_ws(3, maxact))) return rc;
@@ -1094,7 +1148,8 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
         prof.end();
         if (!last && colors && colors[i]) {  // colour layer of this level (_autoencoders.py:417-436, :448-449)
             if (!l.color_wp) return fail(CAE_ERR_ARG, "colour layer %d not set", i);
-            if (f16) return fail(CAE_ERR_UNSUPPORTED, "multiscale colour layers run on the fp32 path: set precision 0");
+            if (f16 && !l.color_wp16)
+                return fail(CAE_ERR_UNSUPPORTED, "f16x3: colour layers to more than 32 channels run on the fp32 path: set precision 0");
             LayerArgs c{};
             c.in = (const float *)a.out;
             c.out = colors[i];
@@ -1115,7 +1170,15 @@ static int synthesis_impl(cae_model_t *mm, const float *latents, const int32_t *
             c.tiles_y = (a.OH + 2 * CAE_CONV_NW - 1) / (2 * CAE_CONV_NW);
             c.outfmt = OUT_NCHW;
             c.act = 0;
-            if ((rc = launch_conv_s1(m->ks, round_ct(l.color_cout), false, false, c, st))) return rc;
+            if (f16) {  // split rows in (C8SP), reflect padding, NCHW fp32 out
+                c.wp = (const float *)l.color_wp16;
+                c.cci = (l.cout + 15) / 16;
+                c.tiles_y = (a.OH + 15) / 16;
+                c.flag = flag;
+                if ((rc = launch_color_f16(m->ks, c, st))) return rc;
+            } else if ((rc = launch_conv_s1(m->ks, round_ct(l.color_cout), false, false, c, st))) {
+                return rc;
+            }
         }
         if (!last && bridges && bridges[i]) {
             const size_t t2 = (size_t)n * l.cout * a.OH * a.OW;

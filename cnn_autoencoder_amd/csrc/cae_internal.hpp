@@ -25,7 +25,8 @@ struct Layer {
     // LeakyReLU / ReLU units and the res_model of the residual units (_autoencoders.py:62-76, :104-174, :230-304)
     struct Stage {
         float *wp = nullptr, *bias = nullptr, *gp = nullptr, *beta = nullptr;
-        void *wp16 = nullptr;  // f16x3 path: packed hi/lo weights (activation stages; GDN / residual stages are fp32 only)
+        void *wp16 = nullptr;  // f16x3 path: packed hi/lo weights
+        void *gp16 = nullptr;  // f16x3 path: packed hi/lo gamma (GDN / IGDN stages of residual units)
         bool gdn = false;      // GDN (analysis) / IGDN (synthesis) after the convolution, else `act`
         int act = 0;
         bool add_res = false;  // + the unit's input after the activation (residual units)
@@ -35,6 +36,7 @@ struct Layer {
     // multiscale colour layer on this synthesis level's output (stride-1 reflect conv to the image channels), or null
     float *color_wp = nullptr;
     float *color_bias = nullptr;
+    void *color_wp16 = nullptr;  // f16x3 path: packed hi/lo weights of the colour layer
     int color_cout = 0;
     int act = 0;               // activation after the pre-convolution and after this layer (0 none, 1 LeakyReLU, 2 ReLU)
     void *wp16 = nullptr;      // f16x3 path: packed hi/lo weights

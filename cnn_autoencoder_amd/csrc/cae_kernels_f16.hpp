@@ -261,14 +261,45 @@ __device__ __forceinline__ void store_split_f16(const f32x16 (&acc)[CT], const L
     }
 }
 
-template <int CT, bool SP = false, bool MAY_ACT = false>
+// Residual units (_autoencoders.py:104-174, :230-304): acc += the unit's input, read from its split rows.  Lane (px, h)
+// owns channels 4h .. 4h+3 of every plane: their hi halves are 8 bytes of the pixel's hi piece, their lo halves the same
+// 8 bytes of the lo piece 512 bytes on, and hi + lo in fp32 is the stored value.  (Two 8-byte loads per plane, not the
+// mirror image of store_split_f16's 16-byte load + v_permlane32_swap: hipcc 7.2 folded the two results of the swap
+// into one -- it emitted 2 hi -- when both were consumed arithmetically in the same lane.)  Then the activation in front
+// of the strided layer (p.post_act).  The unit input may have fewer planes than the stage writes (first analysis unit).
+template <int CT, bool SP>
+__device__ __forceinline__ void add_residual_f16(f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox, int h) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const size_t row_bytes = c8s_row_bytes<SP>(p.OW), plane_bytes = (size_t)p.OH * row_bytes;
+    const char *src = (const char *)p.res + ((size_t)n * p.res_planes * p.OH + oy) * row_bytes + c8s_piece<SP>(ox) + 8 * h;
+    const float slope = p.post_act == 0 ? 1.0f : (p.post_act == 1 ? 0.01f : 0.0f);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (4 * ct + g < p.res_planes) {  // (uniform)
+                const f16x4 hi = *(const f16x4 *)src, lo = *(const f16x4 *)(src + 512);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[ct][4 * g + k] += (float)hi[k] + (float)lo[k];
+            }
+            src += plane_bytes;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = acc[ct][4 * g + k];
+                acc[ct][4 * g + k] = v > 0.0f ? v : slope * v;
+            }
+        }
+}
+
+// EPI: bit 0 = activation (p.act), bit 1 = residual sum + p.post_act (stride-1 stages of residual units)
+template <int CT, bool SP = false, int EPI = 0>
 __device__ __forceinline__ void store_tiles_f16(f32x16 (&acc)[CT], const LayerArgs &p, int n, int oy, int ox,
                                                 int h, bool valid) {
     // (the half-wave exchange of the split store needs both lanes of a pixel: lanes l and l+32 share (oy, ox),
     //  hence the same `valid`; invalid pairs skip the whole store)
     if (!valid) return;
     if (p.outfmt == OUT_C8) {
-        if constexpr (MAY_ACT) {
+        if constexpr (EPI & 1) {
             // LeakyReLU / ReLU units (_autoencoders.py:62-76, :187-202): the activation before the split store, in place and
             // branch-free (slope 1 = no activation; a branch on p.act around the tile made the 192-channel kernels spill).
             // Only the kernels without a fused GDN carry it: GDN units have no other activation.
@@ -278,9 +309,12 @@ __device__ __forceinline__ void store_tiles_f16(f32x16 (&acc)[CT], const LayerAr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ct][r] = acc[ct][r] > 0.0f ? acc[ct][r] : slope * acc[ct][r];
         }
+        if constexpr (EPI & 2) {
+            if (p.res) add_residual_f16<CT, SP>(acc, p, n, oy, ox, h);
+        }
         store_split_f16<CT, SP>(acc, p, n, oy, ox, h);
     } else {
-        store_tiles<CT, false>(acc, p, n, oy, ox, h, valid);  // (last layers: no activation)
+        store_tiles<CT, false>(acc, p, n, oy, ox, h, valid);  // (last layers / colour layers: no activation)
     }
 }
 
@@ -300,7 +334,9 @@ __device__ __forceinline__ void store_tiles_f16(f32x16 (&acc)[CT], const LayerAr
 // staging, WH = 16 + KS - 1 halo columns.  SP: rows in and out are C8SP (synthesis track); ZP: zero padding instead of
 // reflection -- the synthesis units' ConvTranspose2d(stride 1, padding k//2) (:187-202) is the zero-padded correlation
 // with the flipped kernel (flipped when packed).
-template <int KS, int CT, bool GDN, int S = 2, bool SP = false, bool ZP = false>
+// RES: stage of a residual unit -- (I)GDN or activation, + the unit's input, + the strided layer's pre-activation
+// (add_residual_f16); the synthesis units (ZP) normalise with the inverse GDN.
+template <int KS, int CT, bool GDN, int S = 2, bool SP = false, bool ZP = false, bool RES = false>
 __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(const LayerArgs p) {
     constexpr int NW = CAE_CONV_F16_NW, PT = 8 / NW;  // 8 waves x 1 column tile (shipped) | 4 waves x 2
     constexpr int PAD = KS / 2;
@@ -457,12 +493,12 @@ __global__ void __launch_bounds__(CAE_CONV_F16_NW * 64, 1) conv_s2_f16_kernel(co
     }
 
     if constexpr (GDN) {
-        gdn_stages_f16<CT, PT, NW, false, STAGE_BYTES>(acc, p, smem, sc, wave, lane, [](char *) {});
+        gdn_stages_f16<CT, PT, NW, ZP, STAGE_BYTES>(acc, p, smem, sc, wave, lane, [](char *) {});
     }
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int oy = oy0 + 2 * PT * wave + 2 * pt + (m >> 4), ox = ox0 + (m & 15);
-        store_tiles_f16<CT, SP, !GDN>(acc[pt], p, n, oy, ox, h, oy < p.OH && ox < p.OW);
+        store_tiles_f16<CT, SP, (GDN ? 0 : 1) | (RES ? 2 : 0)>(acc[pt], p, n, oy, ox, h, oy < p.OH && ox < p.OW);
     }
 }
 
@@ -1548,7 +1584,8 @@ __global__ void c8s_to_nchw_kernel(const char *in, float *out, int N, int C, int
     }
 }
 
-// fp32 C8 [rows][W][8] -> C8S rows (more than 4 input channels given as uint8: rare)
+// fp32 C8 [rows][W][8] -> C8S rows (more than 4 input channels given as uint8: rare); SP: C8SP rows (synthesis track)
+template <bool SP = false>
 static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t rows, int W, int *flag) {
     const size_t npix = rows * W;
     float mx = 0.0f;
@@ -1566,7 +1603,7 @@ static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t rows,
             vh[4 + k] = x;
             vl[4 + k] = y;
         }
-        char *dst = out + (i / W) * c8s_row_bytes<false>(W) + c8s_piece<false>((int)(i % W));
+        char *dst = out + (i / W) * c8s_row_bytes<SP>(W) + c8s_piece<SP>((int)(i % W));
         *(f16x8 *)dst = vh;
         *(f16x8 *)(dst + 512) = vl;
     }
@@ -1574,10 +1611,11 @@ static __global__ void c8_to_c8s_kernel(const float *in, char *out, size_t rows,
 }
 
 // C8S rows -> fp32 C8 [rows][W][8] (a layer the f16x3 kernels do not cover runs on the fp32 kernel)
+template <bool SP = false>
 static __global__ void c8s_to_c8_kernel(const char *in, float *out, size_t rows, int W) {
     const size_t npix = rows * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
-        const char *src = in + (i / W) * c8s_row_bytes<false>(W) + c8s_piece<false>((int)(i % W));
+        const char *src = in + (i / W) * c8s_row_bytes<SP>(W) + c8s_piece<SP>((int)(i % W));
         const f16x8 vh = *(const f16x8 *)src, vl = *(const f16x8 *)(src + 512);
         f32x4 a, b;
 #pragma unroll

@@ -27,7 +27,8 @@ int launch_first(int ks, int ct, bool gdn, const LayerArgs &a, const FirstArgs &
 int launch_last(int ks, const LayerArgs &a, hipStream_t st);
 int launch_conv_f16(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st);
 int launch_deconv_f16(int ks, int ct, bool gdn, const LayerArgs &a, hipStream_t st);
-int launch_conv_s1_f16(int ks, int ct, bool synthesis, const LayerArgs &a, hipStream_t st);
+int launch_conv_s1_f16(int ks, int ct, bool synthesis, bool gdn, const LayerArgs &a, hipStream_t st);
+int launch_color_f16(int ks, const LayerArgs &a, hipStream_t st);
 int launch_first_f16(int ks, int ct, bool gdn, const LayerArgs &a, const FirstArgs &f, hipStream_t st);
 int launch_last_f16(int ks, const LayerArgs &a, hipStream_t st);
 // GDN / IGDN in place on the split rows a.out (layers wider than 128 channels; a.outfmt must be OUT_C8)

@@ -417,16 +417,17 @@ class _Track(nn.Module):
     def precision_code(self) -> int:
         """0 = exact fp32 MFMA, 1 = f16x3 split MFMA.  Attribute `precision` ('fp32' | 'f16x3'), else the
         CAE_PRECISION environment variable, else 'f16x3' (fp32-class accuracy at ~2x the throughput;
-        GDN layers wider than 128 channels run their normalisation as a separate f16x3 kernel).  Residual units and
-        multiscale colour layers are built on the fp32 kernels only."""
+        GDN layers wider than 128 channels run their normalisation as a separate f16x3 kernel).  Colour layers to more
+        than 32 image channels are built on the fp32 kernels only."""
         import os
         prec = getattr(self, 'precision', None) or os.environ.get('CAE_PRECISION', 'f16x3')
         if prec not in ('fp32', 'f16x3'):
             raise ValueError(f"precision must be 'fp32' or 'f16x3', got {prec!r}")
-        if any(isinstance(u, _ResidualUnit) for u in self._units()):
-            return 0  # residual units: stride-1 stages on the fp32 kernels
-        if getattr(self, 'multiscale_analysis', False):
-            return 0  # colour layers are stride-1 convolutions on the fp32 kernels
+        # (residual units: the split-f16 stride-1 kernel carries the (I)GDN / residual-sum epilogue up to 128 channels; the
+        #  library takes the stages of a wider unit through its fp32 kernels, the strided layers stay on f16x3)
+        # multiscale colour layers: split-f16 stride-1 kernel to at most 32 image channels
+        if getattr(self, 'multiscale_analysis', False) and self._dims[0] > 32:
+            return 0
         # (LeakyReLU / ReLU units: the stride-1 pre-convolutions run on the split-f16 kernel too, conv_s2_f16_kernel<.., S = 1>;
         #  the 192-channel transposed-convolution kernel carries no activation epilogue -- it would spill)
         if self._track_id == _lib.CAE_SYNTHESIS and any(u.act_code and u.main.out_channels > 128 for u in self._units()):

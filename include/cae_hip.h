@@ -128,7 +128,9 @@ int cae_synthesis(cae_model_t *m, const float *latents_dev, int n, int lh, int l
  * (0 or 1) computes  y = post_act( act_or_gdn(conv(x_stage)) [+ unit input] ):  w (cin,cin,k,k) with bias or NULL
  * (BatchNorm folded by the caller), beta/gamma = effective GDN parameters of that stage or NULL, act / post_act as
  * in cae_model_set_layer_act.  cae_model_set_layer_act clears the stages of its layer (and creates stage 0 from
- * its pre-convolution), so call it first.  fp32 path only (precision 0). */
+ * its pre-convolution), so call it first.  Precision 1 (f16x3): GDN / residual stages up to 128 channels run
+ * on conv_s2_f16_kernel<.., S = 1, RES>; the stages of a wider unit run on the fp32 kernels between two layout
+ * conversions (the strided layers stay on f16x3). */
 int cae_model_set_layer_stage(cae_model_t *m, int track, int index, int stage, const float *w, const float *bias,
                               const float *beta, const float *gamma, int act, int add_residual, int post_act);
 
@@ -136,7 +138,7 @@ int cae_model_set_layer_stage(cae_model_t *m, int track, int index, int stage, c
  * convolution from the output of synthesis level `index` (< compression_level-1) to the image channels.
  * w: (cout, cin, k, k).  cae_synthesis_multiscale additionally writes colors_dev[i] (n, cout, lh*2^(i+1),
  * lw*2^(i+1)) float NCHW for every non-NULL entry: the reference's x_r[compression_level-1-i]
- * (_autoencoders.py:446-452).  fp32 path only (precision 0). */
+ * (_autoencoders.py:446-452).  Precision 1 (f16x3): colour layers to at most 32 channels; wider: precision 0. */
 int cae_model_set_color_layer(cae_model_t *m, int index, int cin, int cout, const float *w, const float *bias);
 int cae_synthesis_multiscale(cae_model_t *m, const float *latents_dev, int n, int lh, int lw, void *out_dev, int fmt,
                              float *const *bridges_dev, float *const *colors_dev, void *stream);

@@ -335,6 +335,30 @@ def test_activation_units_stay_on_the_selected_arithmetic(cae, name, precision):
         assert eff.value == want and track.fp32_fallbacks == 0
 
 
+@pytest.mark.parametrize('name', ['var_res_gdn_40x56', 'var_res_lrelu_bn_bias_37x45', 'var_res_none_k5_48x48',
+                                  'var_res_relu_mid_32x32', 'var_multiscale_lrelu_bias_40x56', 'var_multiscale_gdn_k5_48x48'])
+def test_residual_and_multiscale_units_stay_on_the_selected_arithmetic(cae, name, precision):
+    """Residual units (stride-1 stages with an (I)GDN / activation + residual-sum epilogue, _autoencoders.py:104-174,
+    :230-304) and the multiscale colour layers (:417-436) run on the split-f16 stride-1 kernel when f16x3 is selected
+    (rounds 1-2 sent them to the fp32 kernels): the handle reports the arithmetic in use and no fp32 repeat happens.
+    (Their outputs against the reference's are test_variant_goldens, which runs under both precisions.)"""
+    import ctypes
+    from test_host import variant_modules
+    from cnn_autoencoder_amd import _lib
+    g, cfg = load_golden(name)
+    enc, dec = variant_modules(cae, g, cfg)
+    want = 1 if precision == 'f16x3' else 0
+    assert enc.precision_code() == want and dec.precision_code() == want
+    x = torch.from_numpy(g['tile']).permute(2, 0, 1).unsqueeze(0).float() / 255.0
+    y = enc.cuda()(x.cuda()).cpu().numpy()
+    np.testing.assert_allclose(y, g['y'], rtol=RTOL, atol=ATOL)
+    dec.cuda()(torch.round(torch.from_numpy(g['y'])).cuda())
+    for track in (enc, dec):
+        eff = ctypes.c_int(-1)
+        _lib.check(_lib.lib().cae_model_effective_precision(track._sync().ptr, ctypes.byref(eff)))
+        assert eff.value == want and track.fp32_fallbacks == 0
+
+
 @pytest.mark.parametrize('kind', ['histo', 'uniform'])
 def test_full_size_tile_against_the_oracle(cae, kind, precision):
     """BASELINE's tile size (canonical 128/192/L4 model, one 1024x1024x3 tile of each synthetic kind), both arithmetic

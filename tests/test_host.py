@@ -229,7 +229,9 @@ def test_init_and_state_dict_keys_match_reference_fixture(cae):
 def test_unsupported_variants_say_so(cae):
     with pytest.raises(NotImplementedError):
         cae.Analyzer(3, 8, 16, 3, kernel_size=7)
-    assert cae.Analyzer(3, 8, 16, 3, use_residual=True, act_layer_type='GDN').precision_code() == 0  # fp32 kernels
+    # residual units ride the split-f16 kernels (stages wider than 128 channels detour through fp32 inside the library)
+    assert cae.Analyzer(3, 8, 16, 3, use_residual=True, act_layer_type='GDN').precision_code() == 1
+    assert cae.Analyzer(3, 160, 16, 3, use_residual=True, act_layer_type='GDN').precision_code() == 1
     with pytest.raises(ValueError, match='not supported'):  # the reference's own message (_autoencoders.py:32)
         cae.Analyzer(3, 8, 16, 3, act_layer_type='LeakyRelU')
     with pytest.raises(ValueError, match='divisible by groups'):  # nn.Conv2d's own condition (3 -> 8, groups=3)
@@ -238,9 +240,10 @@ def test_unsupported_variants_say_so(cae):
     a = cae.Analyzer(3, 8, 16, 3, act_layer_type='LeakyReLU', bias=True)
     assert list(a.state_dict()) == [f'analysis_track.{i}.model.{j}.{p}' for i, js in ((0, (0, 2)), (1, (0, 2)), (2, (0,)))
                                     for j in js for p in ('weight', 'bias')]
-    assert a.precision_code() == 1  # (round 3: on the split-f16 kernels like the GDN model; residual units are not)
+    assert a.precision_code() == 1  # (round 3: on the split-f16 kernels like the GDN model)
     assert cae.Synthesizer(3, 160, 16, 3, act_layer_type='ReLU').precision_code() == 0  # > 128 channels with an activation
-    assert cae.Synthesizer(3, 8, 16, 3, multiscale_analysis=True).precision_code() == 0  # colour layers: fp32 kernels
+    assert cae.Synthesizer(3, 8, 16, 3, multiscale_analysis=True).precision_code() == 1  # colour layers: <= 32 image channels
+    assert cae.Synthesizer(40, 8, 16, 3, multiscale_analysis=True).precision_code() == 0
     with pytest.raises(NotImplementedError, match='training mode'):  # BatchNorm folds in eval mode only
         cae.Analyzer(3, 8, 16, 3, batch_norm=True).train().analysis_track[0].effective_main()
 
