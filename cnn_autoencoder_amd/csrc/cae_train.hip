@@ -43,6 +43,40 @@ int launch_gg_tp(const GGArgs &a, size_t lds, hipStream_t st) {
     return CAE_OK;
 }
 
+// gg8_kernel (two waves per SIMD, compile-time taps, blocks walking several samples): the shapes of the canonical model
+template <int NT, int NQ, int NTAPS>
+int launch_gg8(GGArgs &a, hipStream_t st) {
+    auto kern = gg8_kernel<NT, NQ, NTAPS>;
+    const size_t h_instr = (size_t)(NQ * a.HR * a.HC + 63) / 64;
+    const size_t lds = 2 * (h_instr + (size_t)NTAPS * NT * (NQ / 2)) * 1024;
+    static size_t attr = 0;
+    if (lds > attr) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    // samples per block: enough blocks for two rounds over the 256 CUs, the rest of the batch amortises a block's prologue
+    const size_t tiles = (size_t)a.tiles_x * a.tiles_y;
+    static const int forced = std::getenv("CAE_GG8_NPB") ? std::atoi(std::getenv("CAE_GG8_NPB")) : 0;
+    a.npb = forced > 0 ? std::min(forced, a.N) : (int)std::min<size_t>(std::max<size_t>((size_t)a.N * tiles / 512, 1), (size_t)a.N);
+    const unsigned grid = (unsigned)(tiles * (size_t)((a.N + a.npb - 1) / a.npb));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+// -> true when a gg8 instantiation covers the launch (rc holds its result)
+bool try_gg8(GGArgs &a, int NT, hipStream_t st, int &rc) {
+    static const char *e8 = std::getenv("CAE_GG8");
+    static const bool off = std::getenv("CAE_GG_LEGACY") != nullptr || (e8 && e8[0] == '0');
+    if (off || a.nq == 0 || (a.nq * a.HR * a.HC + 63) / 64 > 80) return false;
+    if (NT == 4 && a.nq == 2 && a.ntaps == 9) { rc = launch_gg8<4, 2, 9>(a, st); return true; }
+    if (NT == 4 && a.nq == 4 && a.ntaps == 4) { rc = launch_gg8<4, 4, 4>(a, st); return true; }
+    if (NT == 4 && a.nq == 4 && a.ntaps == 2) { rc = launch_gg8<4, 4, 2>(a, st); return true; }
+    if (NT == 4 && a.nq == 4 && a.ntaps == 1) { rc = launch_gg8<4, 4, 1>(a, st); return true; }
+    if (NT == 1 && a.nq == 4 && a.ntaps == 1) { rc = launch_gg8<1, 4, 1>(a, st); return true; }
+    return false;
+}
+
 template <int NT>
 int launch_gg_t(const GGArgs &a, size_t lds, hipStream_t st) {
     return a.nq ? launch_gg_tp<NT, true>(a, lds, st) : launch_gg_tp<NT, false>(a, lds, st);
@@ -87,6 +121,8 @@ int launch_gg(GGArgs &a, hipStream_t st) {
     a.tiles_y = (a.LH + 15) / 16;
     a.zero = zero_page();
     if (!a.zero) return fail(CAE_ERR_NOMEM, "zero page");
+    int rc8 = CAE_OK;
+    if (try_gg8(a, NT, st, rc8)) return rc8;
     switch (NT) {
         case 1: return launch_gg_t<1>(a, lds, st);
         case 2: return launch_gg_t<2>(a, lds, st);

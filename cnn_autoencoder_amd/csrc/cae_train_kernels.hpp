@@ -80,6 +80,7 @@ struct GGArgs {
     int taps_per_stage;
     unsigned m_plane, m_hc;  // ceil(2^32 / (HR * HC)), ceil(2^32 / HC): exact quotients of piece indices by __umulhi
     int nq;             // pipelined form: 8-channel quarters of the contraction per staged slice (4 = a chunk, 2 = half), else 0
+    int npb;            // gg8_kernel: consecutive samples a block walks (same tile of each)
     int tiles_x, tiles_y;
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
 };
@@ -277,6 +278,158 @@ __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
             }
         });
     });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gg8: the gather-GEMM with TWO waves per SIMD and blocks that live for several samples (round 3, late).
+//   gather_gemm_kernel above ran at 0.11 of the bf16 MFMA peak on the canonical 128 -> 128 layers: one wave per SIMD walks
+//   DMA issue, barrier, operand reads and MFMAs in order, the tap loop has a run-time trip count (scalar loads of the tap
+//   table inside it, waits that also drain the LDS queue), and a block lives for ONE 16 x 16 tile, so its prologue (the
+//   source offset of every halo piece), the pipeline fill and the drain are paid per tile (26 us of a 70-us block with MFMAs,
+//   DMA, operand addressing and stores all ablated, profiles/r03_experiments.md 4).
+//   Here: 8 waves, wave w = rows 2w, 2w+1 of the tile = ONE m-tile x all NT n-tiles (1 + NT operand reads per NT MFMAs; the
+//   LDS feeds that at 0.8 of the MFMA peak); tap count NTAPS and slice width NQ are template parameters, the slice body is fully
+//   unrolled with the tap offsets in scalar registers; a block walks the same tile of p.npb consecutive samples -- the halo
+//   offsets depend on (ty, tx) only -- as one continuous slice pipeline: sample n + 1's first slice is in flight while
+//   sample n's last slice multiplies and its tile is stored.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, int NQ, int NTAPS>
+__global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
+    constexpr int NW = 8, KSTEPS = NQ / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n0 = (bid / p.tiles_y) * p.npb;
+    const int nsamp = min(p.npb, p.N - n0);
+    const int i0 = ty * 16, j0 = tx * 16;
+
+    const int plane = p.HR * p.HC;  // pieces per 8-channel quarter
+    const int hpieces = NQ * plane, h_instr = (hpieces + 63) / 64;
+    constexpr int W_INSTR = NTAPS * NT * KSTEPS;
+    const size_t buf_bytes = (size_t)(h_instr + W_INSTR) * 1024;
+    const size_t sample_bytes = (size_t)p.IH * p.IW * p.Ck * 2;
+
+    // this thread's halo pieces of a slice: byte offset inside the sample, or ~0 = zeros
+    constexpr int MAXP = 10;  // 80 LDS-DMA instructions (80 KiB of halo) over 8 waves
+    unsigned hoff[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        int pc = (wave + i * NW) * 64 + lane;
+        pc = pc < hpieces ? pc : hpieces - 1;
+        const int quarter = (int)__umulhi((unsigned)pc, p.m_plane);
+        const int rem = pc - quarter * plane;
+        const int r = (int)__umulhi((unsigned)rem, p.m_hc), c = rem - r * p.HC;
+        int iy = p.S * i0 + p.dymin + r, ix = p.S * j0 + p.dxmin + c;
+        bool ok = true;
+        if (p.reflect) {
+            iy = reflect_idx(iy, p.IH);
+            ix = reflect_idx(ix, p.IW);
+        } else {
+            ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        }
+        hoff[i] = ok ? (unsigned)((iy * p.IW + ix) * p.Ck * 2 + quarter * 16) : 0xFFFFFFFFu;
+    }
+    // this thread's weight pieces of a slice, relative to the slice's first k-step: [tap][nt][k-step of the slice]
+    constexpr int MAXW = (W_INSTR + NW - 1) / NW;
+    unsigned woff[MAXW];
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) {
+        int f = wave + NW * i;
+        f = f < W_INSTR ? f : W_INSTR - 1;
+        const int tl = f / (NT * KSTEPS), rest = f - tl * (NT * KSTEPS);
+        const int nt = rest / KSTEPS, ks = rest - nt * KSTEPS;
+        woff[i] = (unsigned)(((p.wt[tl] * (NT * 2) + nt * 2 + ks) * 1024) + lane * 16);
+    }
+    const unsigned chunk_bytes = (unsigned)p.ktaps * (NT * 2) * 1024;
+    const int slices = p.Ck / (8 * NQ);
+    constexpr int PER_CHUNK = 4 / NQ;
+
+    auto issue = [&](int ns, int sl, char *buf) {  // slice sl of the block's sample ns
+        const int q = sl / PER_CHUNK, s0 = (sl - q * PER_CHUNK) * KSTEPS;
+        const char *in_s = (const char *)p.in + (size_t)(n0 + ns) * sample_bytes + sl * (16 * NQ);
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int j = wave + i * NW;
+            if (j < h_instr) glds16(hoff[i] != 0xFFFFFFFFu ? (const void *)(in_s + hoff[i]) : p.zero, buf + j * 1024);
+        }
+        char *wb = buf + (size_t)h_instr * 1024;
+        const char *wsrc = (const char *)p.wp + (size_t)q * chunk_bytes + s0 * 1024;
+#pragma unroll
+        for (int i = 0; i < MAXW; ++i) {
+            const int f = wave + NW * i;
+            if (f < W_INSTR) glds16(wsrc + woff[i], wb + f * 1024);
+        }
+    };
+
+    f32x16 acc[NT];
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float b = p.bias ? p.bias[32 * nt + m] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = b;
+        }
+    };
+    init_acc();
+
+    // A operand: position (2 wave + (m >> 4), m & 15), quarter 2 ks + h of the slice, tap offset added per tap (uniform)
+    const int a_base = ((h * p.HR + p.S * (2 * wave + (m >> 4))) * p.HC + p.S * (m & 15)) * 16;
+    const int a_kstep = 2 * plane * 16;
+
+    const int total = nsamp * slices;
+    issue(0, 0, smem);
+    int ns = 0, sl = 0;
+    for (int it = 0; it < total; ++it) {
+        char *cur = smem + (size_t)(it & 1) * buf_bytes;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slice `it` landed; the other buffer's readers are done
+        if (it + 1 < total) {
+            const bool wrap = sl + 1 == slices;
+            issue(wrap ? ns + 1 : ns, wrap ? 0 : sl + 1, smem + (size_t)((it + 1) & 1) * buf_bytes);
+        }
+        const char *ab = cur + a_base;
+        const char *wb = cur + (size_t)h_instr * 1024 + lane * 16;
+        static_for<NTAPS>([&](auto t_tag) __attribute__((always_inline)) {
+            constexpr int t = decltype(t_tag)::value;
+            const int toff = ((p.dy[t] - p.dymin) * p.HC + (p.dx[t] - p.dxmin)) * 16;  // (uniform; kernel-argument loads, hoisted)
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const bf16x8 a = *(const bf16x8 *)(ab + toff + ks * a_kstep);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 b = *(const bf16x8 *)(wb + ((t * NT + nt) * KSTEPS + ks) * 1024);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
+                }
+            }
+        });
+        if (++sl == slices) {
+            // D: lane = output channel 32 nt + m, register r = position acc_row(r) + 4h of the wave's m-tile
+            const int n = n0 + ns;
+            static_for<16>([&](auto r_tag) __attribute__((always_inline)) {
+                constexpr int r = decltype(r_tag)::value;
+                const int mp = acc_row(r) + 4 * h;
+                const int li = i0 + 2 * wave + (mp >> 4), lj = j0 + (mp & 15);
+                const int oy = p.SO * li + p.oy0, ox = p.SO * lj + p.ox0;
+                if (li < p.LH && lj < p.LW && oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
+                    const size_t base = (((size_t)n * p.OH + oy) * p.OW + ox) * p.Cn + m;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float v = acc[nt][r];
+                        if (p.act) v = v > 0.0f ? v : (p.act == 1 ? 0.01f * v : 0.0f);
+                        if (p.out32) p.out32[base + 32 * nt] = v;
+                        if (p.out16) ((__bf16 *)p.out16)[base + 32 * nt] = (__bf16)v;
+                    }
+                }
+            });
+            init_acc();
+            sl = 0;
+            ++ns;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
