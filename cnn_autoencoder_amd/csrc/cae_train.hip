@@ -568,6 +568,25 @@ static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const voi
     HIP_TRY(hipMemsetAsync(gw32, 0, (size_t)a.kk * ca * cb * sizeof(float), st));
     const size_t lds = (size_t)((a.HR * a.HC * 4 + 63) / 64) * 1024 + (size_t)((128 * (cb / 8) + 63) / 64) * 1024;
     const int a_tiles = ca / 32, tap_groups = (a.kk + 8) / 9;
+    {
+        // wgrad8_kernel: 8 waves, double-buffered samples; needs two staging buffers in the LDS and Cb <= 128
+        static const char *e8 = std::getenv("CAE_WG8");
+        const int x_instr = (a.HR * a.HC * 4 + 63) / 64, y_instr = (128 * (cb / 8) + 63) / 64;
+        const size_t lds8 = 2 * (size_t)(x_instr + y_instr) * 1024;
+        if (!(e8 && e8[0] == '0') && cb <= 128 && x_instr <= 64 && lds8 <= 160 * 1024) {
+            static size_t attr = 0;
+            if (lds8 > attr) {
+                HIP_TRY(hipFuncSetAttribute((const void *)wgrad8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+                attr = lds8;
+            }
+            const int tpi = a.tiles_x * a.tiles_y;
+            // sample lanes: about two rounds of blocks over the 256 CUs, each block walking n, n + step, ...
+            const int step = std::max(1, std::min(n, 512 / std::max(1, tpi * a_tiles * tap_groups)));
+            hipLaunchKernelGGL(wgrad8_kernel, dim3(tpi * step, a_tiles, tap_groups), dim3(512), lds8, st, a, tpi, step);
+            HIP_TRY(hipGetLastError());
+            return CAE_OK;
+        }
+    }
     const int ksplit = std::max(1, std::min(a.total_tiles, 512 / (a_tiles * tap_groups)));
     if (cb / 32 <= 4) return launch_wg_t<1>(a, lds, ksplit, a_tiles, tap_groups, st);
     return launch_wg_t<2>(a, lds, ksplit, a_tiles, tap_groups, st);

@@ -23,6 +23,9 @@
 #pragma once
 #include "cae_kernels.hpp"
 
+#ifndef GG8_ABL
+#define GG8_ABL 0  // timing experiments on gg8_kernel (results wrong): bit 0 no MFMA, 1 no LDS-DMA after the first slice, 2 no stores
+#endif
 #ifndef GG_ABL
 #define GG_ABL 0  // timing experiments on gather_gemm (results wrong): bit 0 no MFMA, 1 no LDS-DMA after the first slice,
 #endif            // 2 operand reads from one fixed LDS address, 3 no output stores
@@ -321,8 +324,10 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
     for (int i = 0; i < MAXP; ++i) {
         int pc = (wave + i * NW) * 64 + lane;
         pc = pc < hpieces ? pc : hpieces - 1;
-        const int quarter = (int)__umulhi((unsigned)pc, p.m_plane);
-        const int rem = pc - quarter * plane;
+        // pixel-major: the NQ 16-byte quarters of a pixel's slice sit on consecutive lanes = one 32- or 64-byte run of its
+        // channel vector (quarter-major, one lane per cache line and every line fetched NQ times, held the kernel at the
+        // rate of its LDS-DMA: 0.38 ms with, 0.17 ms without the copies on the 128 -> 128 layer)
+        const int quarter = pc % NQ, rem = pc / NQ;
         const int r = (int)__umulhi((unsigned)rem, p.m_hc), c = rem - r * p.HC;
         int iy = p.S * i0 + p.dymin + r, ix = p.S * j0 + p.dxmin + c;
         bool ok = true;
@@ -377,9 +382,9 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
     };
     init_acc();
 
-    // A operand: position (2 wave + (m >> 4), m & 15), quarter 2 ks + h of the slice, tap offset added per tap (uniform)
-    const int a_base = ((h * p.HR + p.S * (2 * wave + (m >> 4))) * p.HC + p.S * (m & 15)) * 16;
-    const int a_kstep = 2 * plane * 16;
+    // A operand: halo [row][col][quarter]; position (2 wave + (m >> 4), m & 15), quarter 2 ks + h, tap offset per tap (uniform)
+    const int a_base = (((p.S * (2 * wave + (m >> 4))) * p.HC + p.S * (m & 15)) * NQ + h) * 16;
+    constexpr int a_kstep = 2 * 16;
 
     const int total = nsamp * slices;
     issue(0, 0, smem);
@@ -387,7 +392,7 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
     for (int it = 0; it < total; ++it) {
         char *cur = smem + (size_t)(it & 1) * buf_bytes;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slice `it` landed; the other buffer's readers are done
-        if (it + 1 < total) {
+        if (it + 1 < total && !(GG8_ABL & 2)) {
             const bool wrap = sl + 1 == slices;
             issue(wrap ? ns + 1 : ns, wrap ? 0 : sl + 1, smem + (size_t)((it + 1) & 1) * buf_bytes);
         }
@@ -395,14 +400,17 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
         const char *wb = cur + (size_t)h_instr * 1024 + lane * 16;
         static_for<NTAPS>([&](auto t_tag) __attribute__((always_inline)) {
             constexpr int t = decltype(t_tag)::value;
-            const int toff = ((p.dy[t] - p.dymin) * p.HC + (p.dx[t] - p.dxmin)) * 16;  // (uniform; kernel-argument loads, hoisted)
+            const int toff = ((p.dy[t] - p.dymin) * p.HC + (p.dx[t] - p.dxmin)) * (NQ * 16);  // (uniform; kernel-argument loads, hoisted)
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 const bf16x8 a = *(const bf16x8 *)(ab + toff + ks * a_kstep);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const bf16x8 b = *(const bf16x8 *)(wb + ((t * NT + nt) * KSTEPS + ks) * 1024);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
+                    if (GG8_ABL & 1)
+                        acc[nt][0] += (float)a[0] * (float)b[0];
+                    else
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
                 }
             }
         });
@@ -414,7 +422,7 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
                 const int mp = acc_row(r) + 4 * h;
                 const int li = i0 + 2 * wave + (mp >> 4), lj = j0 + (mp & 15);
                 const int oy = p.SO * li + p.oy0, ox = p.SO * lj + p.ox0;
-                if (li < p.LH && lj < p.LW && oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
+                if (li < p.LH && lj < p.LW && oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW && (!(GG8_ABL & 4) || p.N < 0)) {
                     const size_t base = (((size_t)n * p.OH + oy) * p.OW + ox) * p.Cn + m;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
@@ -576,6 +584,143 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const WGArgs p) {
             }
         }
     });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad8: wgrad_kernel with two waves per SIMD and a double-buffered tile pipeline (round 3, late).
+//   wgrad_kernel stages a tile, waits, multiplies, and starts over (one wave per SIMD, source offsets recomputed per tile):
+//   0.07 of the bf16 MFMA peak on the 128 -> 128 layers.  Here a block owns ONE tile position (ty, tx) and walks samples
+//   n = first, first + step, ...: the source offsets of its staging pieces are computed once; sample k + 1 is on its way by
+//   LDS-DMA while sample k multiplies; 8 waves = 2 position groups (tile rows 4 kg .. 4 kg + 3) x 4 b-tiles, every wave
+//   with its own partial sums (9 taps x 16 registers), flushed by atomics at the end as before.  Cb <= 128.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 1) wgrad8_kernel(const WGArgs p, int tiles_per_image, int sample_step) {
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wb = wave & 3, kg = wave >> 2;
+    const int at = blockIdx.y;
+    const int tap0 = blockIdx.z * 9;
+    const int ntaps = min(9, p.kk - tap0);
+    const int nbt = p.Cb / 32;
+
+    const int x_pieces = p.HR * p.HC * 4;  // pixel-major: 4 x 16 B per pixel (32 channels of the a-tile)
+    const int x_instr = (x_pieces + 63) / 64;
+    const int ypp = p.Cb / 8;              // 16-byte pieces per position
+    const int y_pieces = 128 * ypp;
+    const int y_instr = (y_pieces + 63) / 64;
+    const size_t buf_bytes = (size_t)(x_instr + y_instr) * 1024;
+
+    const int tp = blockIdx.x % tiles_per_image, n_first = blockIdx.x / tiles_per_image;
+    const int tx = tp % p.tiles_x, ty = tp / p.tiles_x;
+    const int i0 = ty * 8, j0 = tx * 16;
+
+    // source offsets of this thread's staging pieces inside a sample (~0 = zeros), once per block
+    constexpr int MAXX = 8, MAXY = 4;  // <= 64 KiB of X halo, 32 KiB of Y (Cb <= 128)
+    unsigned xoff[MAXX], yoff[MAXY];
+#pragma unroll
+    for (int i = 0; i < MAXX; ++i) {
+        int pc = (wave + i * NW) * 64 + lane;
+        pc = pc < x_pieces ? pc : x_pieces - 1;
+        const int pix = pc >> 2, quarter = pc & 3;
+        const int r = (int)__umulhi((unsigned)pix, p.m_hc), c = pix - r * p.HC;
+        int iy = p.S * i0 + p.dymin + r, ix = p.S * j0 + p.dxmin + c;
+        bool ok = true;
+        if (p.reflect) {
+            iy = reflect_idx(iy, p.H);
+            ix = reflect_idx(ix, p.W);
+        } else {
+            ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        }
+        xoff[i] = ok ? (unsigned)(((iy * p.W + ix) * p.Ca + 32 * at) * 2 + quarter * 16) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXY; ++i) {
+        int pc = (wave + i * NW) * 64 + lane;
+        pc = pc < y_pieces ? pc : y_pieces - 1;
+        const int pos = (int)__umulhi((unsigned)pc, p.m_ypp), part = pc - pos * ypp;
+        const int i_ = i0 + (pos >> 4), jj = j0 + (pos & 15);
+        const bool ok = i_ < p.OH && jj < p.OW;  // positions outside contribute zero
+        yoff[i] = ok ? (unsigned)(((i_ * p.OW + jj) * p.Cb) * 2 + part * 16) : 0xFFFFFFFFu;
+    }
+    const size_t x_sample = (size_t)p.H * p.W * p.Ca * 2, y_sample = (size_t)p.OH * p.OW * p.Cb * 2;
+    auto issue = [&](int n, char *buf) {
+        const char *x_n = (const char *)p.x + (size_t)n * x_sample;
+#pragma unroll
+        for (int i = 0; i < MAXX; ++i) {
+            const int j = wave + i * NW;
+            if (j < x_instr) glds16(xoff[i] != 0xFFFFFFFFu ? (const void *)(x_n + xoff[i]) : p.zero, buf + j * 1024);
+        }
+        const char *y_n = (const char *)p.y + (size_t)n * y_sample;
+        char *yb = buf + (size_t)x_instr * 1024;
+#pragma unroll
+        for (int i = 0; i < MAXY; ++i) {
+            const int j = wave + i * NW;
+            if (j < y_instr) glds16(yoff[i] != 0xFFFFFFFFu ? (const void *)(y_n + yoff[i]) : p.zero, yb + j * 1024);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // transposed reads: 16-lane group g: channel half g&1, k-group g>>1; lane 4q+pp of the group addresses row q
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+    const int col_off = (16 * (g & 1) + 4 * pp) * 2;  // bytes inside a 32-channel record
+    const int lj0 = 8 * (g >> 1) + q4, lj1 = lj0 + 4;  // this lane's columns of the two 4-row blocks of a 16-position k-step
+    const int btc = wb < nbt ? wb : 0;
+
+    if (n_first < p.N) issue(n_first, smem);
+    int it = 0;
+    for (int n = n_first; n < p.N; n += sample_step, ++it) {
+        char *cur = smem + (size_t)(it & 1) * buf_bytes;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // sample n landed; the other buffer's readers are done
+        if (n + sample_step < p.N) issue(n + sample_step, smem + (size_t)((it + 1) & 1) * buf_bytes);
+        const char *xbuf = cur, *ybuf = cur + (size_t)x_instr * 1024;
+#pragma unroll 2
+        for (int kq = 0; kq < 4; ++kq) {  // 16 positions: tile row ks, columns 0..15
+            const int ks = 4 * kg + kq;
+            const char *yb = ybuf + (size_t)(16 * ks) * p.Cb * 2 + 64 * btc + col_off;
+            const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4 *)(yb + (size_t)lj0 * p.Cb * 2));
+            const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4 *)(yb + (size_t)lj1 * p.Cb * 2));
+            const short bv[8] = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+            const bf16x8 bfr = __builtin_bit_cast(bf16x8, bv);
+            static_for<9>([&](auto t_tag) __attribute__((always_inline)) {
+                constexpr int t = decltype(t_tag)::value;
+                if (t < ntaps) {
+                    const int hr = p.S * ks + p.dy[tap0 + t] - p.dymin;
+                    const int hc = p.dx[tap0 + t] - p.dxmin;
+                    const char *xb = xbuf + (size_t)(hr * p.HC + hc) * 64 + col_off;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(xb + p.S * lj0 * 64));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(xb + p.S * lj1 * 64));
+                    const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), bfr, acc[t], 0, 0, 0);
+                }
+            });
+        }
+    }
+
+    // D: register r = a-channel acc_row(r) + 4h of the a-tile, lane = b-channel
+    const int h = lane >> 5, m = lane & 31;
+    if (wb < nbt) {
+        static_for<9>([&](auto t_tag) __attribute__((always_inline)) {
+            constexpr int t = decltype(t_tag)::value;
+            if (t < ntaps) {
+                static_for<16>([&](auto r_tag) __attribute__((always_inline)) {
+                    constexpr int r = decltype(r_tag)::value;
+                    const int a = 32 * at + acc_row(r) + 4 * h;
+                    atomicAdd(p.gw + ((size_t)(tap0 + t) * p.Ca + a) * p.Cb + 32 * wb + m, acc[t][r]);
+                });
+            }
+        });
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
