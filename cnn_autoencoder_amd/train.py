@@ -19,7 +19,8 @@ What the reference's training step does (``src/train_cae_ms.py:189-262``) and wh
   ``torch.distributed`` (RCCL over xGMI on GPUs, gloo on CPU), one process per GPU.
 
 Variants covered: ``act_layer_type in (None, 'GDN', 'LeakyReLU', 'ReLU')`` units (the last two with their stride-1
-pre-convolutions) without residual branches, batch norm, groups or multiscale colour layers; anything else raises
+pre-convolutions) on the fused track functions, and residual units (``use_residual=True``) composed per operation from
+the same kernels (``_residual_track``); batch norm in training mode, groups, dropout and multiscale colour layers raise
 ``NotImplementedError`` under autograd.
 """
 from __future__ import annotations
@@ -527,6 +528,180 @@ class SynthesisFn(torch.autograd.Function):
         return (g_in, None, *_flat_grads(specs, per_layer))
 
 
+# ---- residual units (ResidualDownsamplingUnit / ResidualUpsamplingUnit, _autoencoders.py:104-174, :230-304) ----------
+# Their tracks are composed per operation, on NCHW fp32 tensors between operations: every convolution and every GDN is
+# one of the kernels above behind a small autograd function of its own, the residual sum and the LeakyReLU / ReLU in
+# front of the strided layer are element-wise torch operations on the unit's tensors.  (The canonical tracks keep their
+# fused functions above; this form pays two layout conversions per operation.)
+
+class _ConvS1Fn(torch.autograd.Function):
+    """Stride-1 convolution cin -> cin of a residual unit's res_model, (+ bias) (+ LeakyReLU / ReLU): analysis = Conv2d with
+    reflect padding, synthesis = ConvTranspose2d(stride 1, padding k//2) (cae_t_corr_s1 modes 0 / 2; backward: cae_t_wgrad_s1
+    and the data gradients of modes 1 / 3)."""
+
+    @staticmethod
+    def forward(ctx, x, synthesis, ks, act, w, b):
+        L = _L()
+        n, c, h, wd = x.shape
+        cp, dev = _pad32(c), x.device
+        a16, _ = _from_nchw(x, cp)
+        wp = _pack(w, 0 if synthesis else 1, ks)
+        bp = _bias_p(b, cp, dev)
+        out32 = torch.empty((n, h, wd, cp), dtype=torch.float32, device=dev)
+        out16 = torch.empty((n, h, wd, cp), dtype=torch.bfloat16, device=dev) if act else None
+        _lib.check(L.cae_t_corr_s1(a16.data_ptr(), n, h, wd, cp, wp.data_ptr(), ks, 2 if synthesis else 0, out32.data_ptr(),
+                                   _ptr(out16), cp, _ptr(bp), act, _st()))
+        ctx.a16, ctx.out16, ctx.w = a16, out16, w.detach()
+        ctx.cfg = (bool(synthesis), int(ks), int(act), b is not None, c)
+        return _to_nchw(out32, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _L()
+        synthesis, ks, act, has_bias, c = ctx.cfg
+        a16 = ctx.a16
+        n, h, wd, cp = a16.shape
+        dev = g.device
+        P = ks // 2
+        if act:  # through the activation on the fp32 gradient (one rounding)
+            g32 = _from_nchw(g, cp, want16=False, want32=True)[1]
+            gu16 = _act_backward(None, g32, 0, ctx.out16, act)
+        else:
+            gu16 = _from_nchw(g, cp)[0]
+        gwp = torch.empty((ks * ks, cp, cp), dtype=torch.float32, device=dev)
+        if synthesis:
+            _lib.check(L.cae_t_wgrad_s1(gu16.data_ptr(), n, h, wd, cp, a16.data_ptr(), cp, ks, 0, gwp.data_ptr(), _st()))
+        else:
+            _lib.check(L.cae_t_wgrad_s1(a16.data_ptr(), n, h, wd, cp, gu16.data_ptr(), cp, ks, 1, gwp.data_ptr(), _st()))
+        g_w = _weight_grad(gwp, (c, c), ks)
+        g_b = _colsum(gu16, c) if has_bias else None
+        if synthesis:
+            wd_p = _pack(ctx.w, 1, ks)
+            gx32 = torch.empty((n, h, wd, cp), dtype=torch.float32, device=dev)
+            _lib.check(L.cae_t_corr_s1(gu16.data_ptr(), n, h, wd, cp, wd_p.data_ptr(), ks, 3, gx32.data_ptr(), None, cp, None, 0,
+                                       _st()))
+            gx = _to_nchw(gx32, c)
+        else:  # extended domain, then the reflect fold
+            wd_p = _pack(ctx.w, 0, ks)
+            gext = torch.empty((n, h + 2 * P, wd + 2 * P, cp), dtype=torch.float32, device=dev)
+            _lib.check(L.cae_t_corr_s1(gu16.data_ptr(), n, h, wd, cp, wd_p.data_ptr(), ks, 1, gext.data_ptr(), None, cp, None, 0,
+                                       _st()))
+            gx16 = torch.empty((n, h, wd, cp), dtype=torch.bfloat16, device=dev)
+            _lib.check(L.cae_t_fold_to_bf16(gext.data_ptr(), n, h, wd, P, cp, gx16.data_ptr(), _st()))
+            gx = _to_nchw(gx16.float(), c)
+        return gx, None, None, None, g_w, g_b
+
+
+class _ConvS2Fn(torch.autograd.Function):
+    """The strided reflect convolution of an analysis unit alone, with its input gradient (AnalysisFn's first layer reads the
+    image and returns none)."""
+
+    @staticmethod
+    def forward(ctx, x, ks, w, b):
+        L = _L()
+        n, c, h, wd = x.shape
+        cout = w.shape[0]
+        cin_p, cout_p, dev = _pad32(c), _pad32(cout), x.device
+        oh, ow = (h + 1) // 2, (wd + 1) // 2
+        a16, _ = _from_nchw(x, cin_p)
+        wp = _pack(w, 1, ks)
+        bp = _bias_p(b, cout_p, dev)
+        z32 = torch.empty((n, oh, ow, cout_p), dtype=torch.float32, device=dev)
+        _lib.check(L.cae_t_conv_forward_act(a16.data_ptr(), n, h, wd, cin_p, wp.data_ptr(), ks, z32.data_ptr(), None, cout_p,
+                                            _ptr(bp), 0, _st()))
+        ctx.a16, ctx.w = a16, w.detach()
+        ctx.cfg = (int(ks), b is not None, c, cout, oh, ow)
+        return _to_nchw(z32, cout)
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _L()
+        ks, has_bias, c, cout, oh, ow = ctx.cfg
+        a16 = ctx.a16
+        n, h, wd, cin_p = a16.shape
+        cout_p, dev, P, kk = _pad32(cout), g.device, ks // 2, ks * ks
+        g16 = _from_nchw(g, cout_p)[0]
+        gw = torch.empty((kk, cin_p, cout_p), dtype=torch.float32, device=dev)
+        _lib.check(L.cae_t_wgrad(a16.data_ptr(), n, h, wd, cin_p, g16.data_ptr(), oh, ow, cout_p, ks, 1, gw.data_ptr(), _st()))
+        g_w = _weight_grad(gw, (cout, c), ks)
+        g_b = _colsum(g16, cout) if has_bias else None
+        wp_d = _pack(ctx.w, 0, ks)
+        gext = torch.empty((n, h + 2 * P, wd + 2 * P, cin_p), dtype=torch.float32, device=dev)
+        _lib.check(L.cae_t_conv_dgrad_ext(g16.data_ptr(), n, oh, ow, cout_p, wp_d.data_ptr(), ks, h, wd, gext.data_ptr(), cin_p,
+                                          _st()))
+        gx16 = torch.empty((n, h, wd, cin_p), dtype=torch.bfloat16, device=dev)
+        _lib.check(L.cae_t_fold_to_bf16(gext.data_ptr(), n, h, wd, P, cin_p, gx16.data_ptr(), _st()))
+        return _to_nchw(gx16.float(), c), None, g_w, g_b
+
+
+class _GdnFn(torch.autograd.Function):
+    """GDN / IGDN alone on an NCHW fp32 tensor (effective, padded beta / gamma): the fused forward / backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, inverse, beta_p, gamma_p):
+        c, cp = x.shape[1], beta_p.numel()
+        z32 = _from_nchw(x, cp, want16=False, want32=True)[1]
+        y16, f = _gdn_forward(z32, beta_p, gamma_p, bool(inverse))
+        ctx.z32, ctx.f, ctx.beta_p, ctx.gamma_p, ctx.cfg = z32, f, beta_p.detach(), gamma_p.detach(), (bool(inverse), c)
+        return _to_nchw(y16.float(), c)
+
+    @staticmethod
+    def backward(ctx, g):
+        inverse, c = ctx.cfg
+        cp = ctx.beta_p.numel()
+        g32 = _from_nchw(g, cp, want16=False, want32=True)[1]  # (the backward kernel works in this buffer)
+        gz16, g_beta, g_gamma = _gdn_backward(ctx.z32, g32, 0, ctx.beta_p, ctx.gamma_p, inverse, ctx.f)
+        return _to_nchw(gz16.float(), c), None, g_beta, g_gamma
+
+
+def _gdn_params(g, c: int):
+    """effective, padded (beta, gamma) of a GDN module, in the autograd graph (LowerBound gradient rule inside)"""
+    cp = _pad32(c)
+    beta, gamma = g.beta_reparam(g.beta), g.gamma_reparam(g.gamma)
+    beta_p = torch.cat([beta, beta.new_ones(cp - c)]) if cp > c else beta
+    gamma_p = torch.nn.functional.pad(gamma, (0, cp - c, 0, cp - c)) if cp > c else gamma
+    return beta_p, gamma_p
+
+
+def _torch_act(t: torch.Tensor, act: int) -> torch.Tensor:
+    return t if not act else (torch.nn.functional.leaky_relu(t, 0.01) if act == 1 else torch.relu(t))
+
+
+def _residual_track(units, x: torch.Tensor, synthesis: bool) -> torch.Tensor:
+    """y = model(res_model(x) + x) per unit (_autoencoders.py:168-174, :298-304)."""
+    for u in units:
+        convs = [u.res_model[ci] for ci, _, _ in u._res] + [u.main]
+        if u.main_bn_index is not None or any(bi is not None for _, bi, _ in u._res) or any(cv.groups != 1 for cv in convs):
+            raise NotImplementedError('training with BatchNorm or grouped layers is not built')
+        if any(isinstance(m, nn.Dropout2d) and m.p > 0 for m in u.model):
+            raise NotImplementedError('training with Dropout2d is not built')
+        cin = u.main.in_channels
+        r = x
+        last = len(u._res) - 1
+        for k, (ci, _, gi) in enumerate(u._res):
+            conv = u.res_model[ci]
+            act = 0 if gi is not None else (u.act_code if (k == 0 or u._second_stage_act) else 0)
+            r = _ConvS1Fn.apply(r, synthesis, conv.kernel_size, act, conv.weight, conv.bias)
+            if gi is not None:
+                r = _GdnFn.apply(r, synthesis, *_gdn_params(u.res_model[gi], cin))
+        r = r + x
+        if last == 1:  # LeakyReLU / ReLU units: the activation in front of the strided layer
+            r = _torch_act(r, u.act_code)
+        conv = u.main
+        if synthesis:
+            spec = LayerSpec(conv.in_channels, conv.out_channels, conv.kernel_size, conv.bias is not None, False)
+            tensors = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
+            y = SynthesisFn.apply(r, (spec,), *tensors)
+        else:
+            y = _ConvS2Fn.apply(r, conv.kernel_size, conv.weight, conv.bias)
+        if u.gdn is not None:
+            y = _GdnFn.apply(y, synthesis, *_gdn_params(u.gdn, conv.out_channels))
+        else:
+            y = _torch_act(y, u.act_code)
+        x = y
+    return x
+
+
 def _track_inputs(track, units, synthesis: bool):
     """-> (specs, flat tensor list) of a track; effective, padded GDN parameters stay in the autograd graph."""
     from .modules import _ResidualUnit
@@ -535,7 +710,7 @@ def _track_inputs(track, units, synthesis: bool):
         raise NotImplementedError('training with multiscale colour layers is not built')
     for u in units:
         if isinstance(u, _ResidualUnit):
-            raise NotImplementedError('training of residual units is not built')
+            return None, None  # composed per operation: _residual_track
         if u.main_bn_index is not None or u.pre_bn_index is not None or u.main.groups != 1:
             raise NotImplementedError('training with BatchNorm or grouped layers is not built')
         conv = u.main
@@ -574,6 +749,8 @@ def analysis_forward(track, x: torch.Tensor) -> torch.Tensor:
     dev = _lib.require_gpu()
     specs, tensors = _track_inputs(track, track._units(), False)
     x = x.to(device=dev, dtype=torch.float32)
+    if specs is None:
+        return _residual_track(track._units(), x, False)
     return AnalysisFn.apply(x, specs, *tensors)
 
 
@@ -581,8 +758,8 @@ def synthesis_forward(track, yq: torch.Tensor):
     dev = _lib.require_gpu()
     specs, tensors = _track_inputs(track, track._units(), True)
     yq = yq.to(device=dev, dtype=torch.float32)
-    out = SynthesisFn.apply(yq, specs, *tensors)
-    L = len(specs)
+    out = _residual_track(track._units(), yq, True) if specs is None else SynthesisFn.apply(yq, specs, *tensors)
+    L = len(track._units())
     # (x_r list, fx_brg) as the reference's Synthesizer; intermediate features are not materialised while training
     return [out] + [None] * (L - 1), [None] * (L - 1) + [out]
 

@@ -124,6 +124,42 @@ def synthesis(y: torch.Tensor, layers: Sequence[dict], bf16: bool = True, act: O
     return fx
 
 
+def residual_track(x: torch.Tensor, units: Sequence[dict], synthesis: bool, bf16: bool = True) -> torch.Tensor:
+    """Residual units (ResidualDownsamplingUnit / ResidualUpsamplingUnit, _autoencoders.py:104-174, :230-304):
+    y = model(res_model(x) + x).  units[i] = {'stages': [{'weight', 'bias'?, 'beta'?, 'gamma'?, 'act'?}], 'post_act'?,
+    'weight', 'bias'?, 'beta'?, 'gamma'?, 'act'?}: res_model = stride-1 convolutions cin -> cin (analysis: reflect padding;
+    synthesis: ConvTranspose2d(stride 1, padding k//2)) each followed by GDN / IGDN or an activation, model = [activation]
+    + the strided layer + GDN / IGDN or activation.  Rounding points of the HIP path (`bf16`): operands of every convolution,
+    the gradient at every convolution's output, the output of every GDN, and the gradient an analysis-side convolution hands to
+    its input (folded from the extended domain into bf16)."""
+    fx = x
+    for U in units:
+        r = fx
+        for S in U['stages']:
+            k = S['weight'].shape[-1]
+            rin = _r(r, bf16) if synthesis else _r(_g(r, bf16), bf16)
+            if synthesis:
+                u = F.conv_transpose2d(rin, _r(S['weight'], bf16), S.get('bias'), stride=1, padding=k // 2)
+            else:
+                u = F.conv2d(F.pad(rin, (k // 2,) * 4, mode='reflect'), _r(S['weight'], bf16), S.get('bias'))
+            u = _g(u, bf16)
+            if S.get('beta') is not None:
+                r = _r(gdn(u, S['beta'], S['gamma'], synthesis), bf16)
+            else:
+                r = _act(u, S.get('act'))
+        r = _act(r + fx, U.get('post_act'))
+        if synthesis:
+            y = _g(O.deconv_s2(_r(r, bf16), _r(U['weight'], bf16), U.get('bias')), bf16)
+        else:
+            y = _g(O.reflect_conv_s2(_r(_g(r, bf16), bf16), _r(U['weight'], bf16), U.get('bias')), bf16)
+        if U.get('beta') is not None:
+            y = _r(gdn(y, U['beta'], U['gamma'], synthesis), bf16)
+        else:
+            y = _act(y, U.get('act'))
+        fx = y
+    return fx
+
+
 def entropy_forward(params: dict, y: torch.Tensor, noise: Optional[torch.Tensor], n_filters: int, form: str = 'plain',
                     bound: float = 1e-9):
     """EntropyBottleneck.forward in train mode: y + noise, likelihood with the LowerBound rule.  noise: like y."""

@@ -65,3 +65,35 @@ def built_lib():
     if not os.path.exists(cae.LIB_PATH):
         cae.build()
     return cae.LIB_PATH
+
+
+def residual_oracle_units(track, act_name):
+    """(oracle unit dicts with leaf clones, [(module parameter name, leaf)]) of a residual track"""
+    units, pairs = [], []
+
+    def leaf(p, name):
+        if p is None:
+            return None
+        t = p.detach().cpu().clone().requires_grad_(True)
+        pairs.append((name, t))
+        return t
+    for i, u in enumerate(track):
+        stages = []
+        for k, (ci, _, gi) in enumerate(u._res):
+            conv = u.res_model[ci]
+            d = dict(weight=leaf(conv.weight, f'{i}.res_model.{ci}.weight'), bias=leaf(conv.bias, f'{i}.res_model.{ci}.bias'))
+            if gi is not None:
+                g = u.res_model[gi]
+                d.update(beta=leaf(g.beta, f'{i}.res_model.{gi}.beta'), gamma=leaf(g.gamma, f'{i}.res_model.{gi}.gamma'))
+            else:
+                d['act'] = act_name if (u.act_code and (k == 0 or u._second_stage_act)) else None
+            stages.append(d)
+        mi = u.main_index
+        d = dict(stages=stages, post_act=act_name if (u.act_code and len(u._res) == 2) else None,
+                 weight=leaf(u.main.weight, f'{i}.model.{mi}.weight'), bias=leaf(u.main.bias, f'{i}.model.{mi}.bias'))
+        if u.gdn is not None:
+            d.update(beta=leaf(u.gdn.beta, f'{i}.model.{u.gdn_index}.beta'), gamma=leaf(u.gdn.gamma, f'{i}.model.{u.gdn_index}.gamma'))
+        else:
+            d['act'] = act_name if u.act_code else None
+        units.append(d)
+    return units, pairs

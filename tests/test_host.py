@@ -538,3 +538,25 @@ def test_training_objective_matches_the_reference_loss_values():
         assert float(loss_o) == pytest.approx(float(g[f'loss_{tag}']), rel=1e-6)
     with pytest.raises(NotImplementedError):
         criteria.setup_loss('RateMSSSIM')
+
+
+@pytest.mark.parametrize('name', ['var_res_gdn_40x56', 'var_res_none_k5_48x48', 'var_res_relu_mid_32x32'])
+def test_residual_training_restatement_is_pinned_by_the_reference_fixtures(cae, name):
+    """oracle/train_oracle.residual_track (the checker of the residual units' gradients, tests/test_train.py) in plain fp32
+    reproduces the outputs the REFERENCE's own ResidualDownsamplingUnit / ResidualUpsamplingUnit stacks produced for the
+    variant fixtures (unit wiring, activation placement, stride-1 transposed convolutions)."""
+    from conftest import load_golden, residual_oracle_units
+    from oracle import train_oracle as T
+    g, cfg = load_golden(name)
+    enc, dec = variant_modules(cae, g, cfg)
+    act = cfg.get('act_layer_type')
+    act_name = act if act in ('LeakyReLU', 'ReLU') else None
+    x = torch.from_numpy(g['tile']).permute(2, 0, 1).unsqueeze(0).float() / 255.0
+    with torch.no_grad():
+        units, _ = residual_oracle_units(enc.analysis_track, act_name)
+        y = T.residual_track(x, units, False, bf16=False)
+        np.testing.assert_allclose(y.numpy(), g['y'], rtol=1e-4, atol=1e-4)
+        units, _ = residual_oracle_units(dec.synthesis_track, act_name)
+        x_r = T.residual_track(torch.round(torch.from_numpy(g['y'])), units, True, bf16=False)
+        scale = max(1.0, float(np.abs(g['x_r_0']).max()))
+        np.testing.assert_allclose(x_r.numpy(), g['x_r_0'], rtol=1e-4, atol=1e-4 * scale)

@@ -260,6 +260,46 @@ def test_track_gradients_match_the_restatement(cae, cfgkw, shape):
                 assert rel(got[name], l[key].grad) < 1e-3, name
 
 
+@pytest.mark.parametrize('act,bias,ks', [('GDN', False, 3), ('LeakyReLU', True, 3), (None, True, 5)])
+def test_residual_unit_gradients_match_the_restatement(cae, act, bias, ks):
+    """Residual units (_autoencoders.py:104-174, :230-304) under autograd: outputs, parameter gradients and the latent
+    gradient of both tracks against torch-CPU autograd of the restatement with the kernels' rounding points."""
+    from oracle import train_oracle as T
+    from conftest import residual_oracle_units
+    torch.manual_seed(11)
+    kw = dict(channels_org=3, channels_net=32, channels_bn=48, compression_level=2, kernel_size=ks, bias=bias,
+              use_residual=True, act_layer_type=act)
+    enc, dec = cae.Analyzer(**kw).cuda().train(), cae.Synthesizer(**kw).cuda().train()
+    with torch.no_grad():  # GDN parameters away from their initial point (off-diagonal gamma exercised)
+        for mod in list(enc.modules()) + list(dec.modules()):
+            if isinstance(mod, cae.GDN):
+                mod.beta.add_(0.1 * torch.rand_like(mod.beta))
+                mod.gamma.add_(0.05 * torch.rand_like(mod.gamma))
+    act_name = act if act in ('LeakyReLU', 'ReLU') else None
+    x = torch.rand(2, 3, 40, 56)
+    for name, mod, track, inp, synthesis in (('analysis', enc, enc.analysis_track, x, False),
+                                             ('synthesis', dec, dec.synthesis_track, 2.0 * torch.randn(2, 48, 5, 7), True)):
+        units, pairs = residual_oracle_units(track, act_name)
+        xin = inp.clone().requires_grad_(True)
+        ref = T.residual_track(xin, units, synthesis, bf16=True)
+        xdev = inp.cuda().requires_grad_(True)
+        out = mod(xdev)
+        out = out[0][0] if synthesis else out
+        assert out.shape == ref.shape
+        g = torch.randn_like(ref.detach())
+        ref.backward(g)
+        out.backward(g.cuda())
+        scale = max(1.0, float(ref.detach().abs().max()))
+        assert float((out.detach().cpu() - ref.detach()).abs().max()) / scale < 2e-3, name
+        if synthesis:
+            assert rel(xdev.grad, xin.grad) < 2.5e-3, name
+        got = {n: p.grad.detach().cpu() for n, p in mod.named_parameters() if p.grad is not None}
+        prefix = 'synthesis_track.' if synthesis else 'analysis_track.'
+        assert len(got) == len(pairs), (sorted(got), [n for n, _ in pairs])
+        for pname, leaf in pairs:
+            assert rel(got[prefix + pname], leaf.grad) < 2.5e-3, (name, pname)
+
+
 def test_fused_clip_adam_equals_the_torch_loop(cae, monkeypatch):
     """cae_t_clip_adam (all optimisers of a step in two launches) against the reference's loop -- clip_grad_norm_(1.0),
     torch.optim.Adam.step(), zero_grad() per optimiser (train_cae_ms.py:221-230) -- on the same gradients, three steps:
@@ -357,12 +397,31 @@ def test_twenty_training_steps_follow_the_restatement(cae):
     assert rel(eb.quantiles.detach().cpu(), eb_ref['quantiles'].detach()) < 1e-3
 
 
+def test_training_steps_of_a_residual_model(cae):
+    """train.train_step on a residual GDN model (use_residual=True): every parameter of both tracks receives a gradient and
+    the rate-distortion loss falls over a few steps on a fixed batch."""
+    from cnn_autoencoder_amd import criteria, train
+    torch.manual_seed(5)
+    model = cae.setup_modules(channels_org=3, channels_net=32, channels_bn=48, compression_level=2, use_residual=True,
+                              act_layer_type='GDN')
+    model = {k: m.cuda().train() for k, m in model.items()}
+    criterion = criteria.GeneralLoss(distortion_lambda=0.01)
+    opts = train.setup_optim(model, learning_rate=1e-3, aux_learning_rate=1e-2)
+    x = torch.rand(4, 3, 48, 64).cuda()
+    before = {n: p.detach().clone() for k in ('encoder', 'decoder') for n, p in model[k].named_parameters()}
+    losses = [float(train.train_step(x, model, criterion, opts)['loss']) for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    moved = [n for k in ('encoder', 'decoder') for n, p in model[k].named_parameters() if not torch.equal(p.detach(), before[n])]
+    assert len(moved) == len(before), sorted(set(before) - set(moved))
+
+
 @pytest.mark.parametrize('form', ['plain', 'sign_trick'])
 def test_fused_density_kernels_match_the_elementwise_graph(cae, form, monkeypatch):
     """cae_t_density_forward / backward (train-mode EntropyBottleneck on the GPU) against the element-wise torch graph of
     the same module (CAE_EB_FUSED=0) and the CPU restatement: outputs, likelihoods (incl. elements clamped at the 1e-9
     bound, where the LowerBound rule decides the gradient), gradient with respect to the input and to every parameter."""
     from oracle import train_oracle as T
+    from conftest import residual_oracle_units
     torch.manual_seed(11)
     c = 40
     eb = cae.EntropyBottleneck(c, likelihood_form=form).cuda().train()
