@@ -99,6 +99,8 @@ SYMBOLS = {
     'cae_t_gdn_backward_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
     'cae_t_fold_to_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cae_t_bn_moments': (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_long, c_void_p, c_void_p, c_void_p]),
+    'cae_t_bn_affine': (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cae_t_colsum': (c_int, [c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p]),
     'cae_t_density_params': (c_int, [c_int, c_int]),
     'cae_t_reparam_forward': (c_int, [c_void_p, ctypes.c_long, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]),

@@ -714,6 +714,30 @@ int cae_t_fold_to_bf16(const float *gext32, int n, int h, int w, int pad, int cp
     return CAE_OK;
 }
 
+int cae_t_bn_moments(const float *a, const float *b, int n, int c, long hw, double *s1, double *s2, void *stream) {
+    if (!a || !b || !s1 || !s2) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || c < 1 || c > 65535 || hw < 1) return fail(CAE_ERR_ARG, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(s1, 0, (size_t)c * sizeof(double), st));
+    HIP_TRY(hipMemsetAsync(s2, 0, (size_t)c * sizeof(double), st));
+    const long total = (long)n * hw;
+    const unsigned splits = (unsigned)std::min<long>(std::max<long>(total / 4096, 1), std::max<long>(2048 / c, 1));
+    hipLaunchKernelGGL(bn_moments_kernel, dim3((unsigned)c, splits), dim3(256), 0, st, a, b, n, c, hw, s1, s2);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+int cae_t_bn_affine(const float *a, const float *b, int n, int c, long hw, const float *A, const float *B, const float *C,
+                    float *out, void *stream) {
+    if (!a || !A || !C || !out || (b && !B)) return fail(CAE_ERR_ARG, "NULL argument");
+    if (n < 1 || c < 1 || hw < 1) return fail(CAE_ERR_ARG, "bad shape");
+    const size_t total = (size_t)n * c * hw;
+    hipLaunchKernelGGL(bn_affine_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, a, b, c, hw, total, A, B, C,
+                       out);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
 int cae_t_colsum(const void *g16, long pixels, int cp, float *out, void *stream) {
     if (!g16 || !out) return fail(CAE_ERR_ARG, "NULL argument");
     if (pixels < 1 || cp % 32 || cp > 256) return fail(CAE_ERR_ARG, "bad shape");

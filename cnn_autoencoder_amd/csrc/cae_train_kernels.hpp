@@ -773,6 +773,54 @@ static __global__ void act_bwd_kernel(const __bf16 *g16, FoldSrc f, const __bf16
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm2d in TRAINING mode (batch statistics; the units' optional nn.BatchNorm2d, _autoencoders.py:72-73, :87-88) on
+// NCHW fp32 tensors.  Both directions are one pair of per-channel moments and one per-channel affine map:
+//   forward   S1 = sum x, S2 = sum x x            y  = x A + C             A = w rstd, C = b - mean A
+//   backward  S1 = sum dy, S2 = sum dy x          dx = dy A + x B + C      (coefficients from S1, S2, mean, rstd: train.py)
+// bn_moments_kernel: grid (C, splits); a block walks its share of the N x HW elements of channel c, sums in double and
+// adds its two partial sums with one double atomic each.
+// ---------------------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) bn_moments_kernel(const float *a, const float *b, int N, int C, long HW,
+                                                                 double *s1, double *s2) {
+    const int c = blockIdx.x;
+    const long per_n = HW, total = (long)N * HW;
+    double t1 = 0.0, t2 = 0.0;
+    for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.y * blockDim.x) {
+        const long n = i / per_n, r = i - n * per_n;
+        const size_t off = ((size_t)n * C + c) * HW + r;
+        const float va = a[off], vb = b[off];
+        t1 += (double)va;
+        t2 += (double)va * (double)vb;
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = t1;
+    red[1][threadIdx.x] = t2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + st];
+            red[1][threadIdx.x] += red[1][threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(s1 + c, red[0][0]);
+        atomicAdd(s2 + c, red[1][0]);
+    }
+}
+
+// out = a A[c] + (b ? b B[c] : 0) + Cc[c]
+static __global__ void bn_affine_kernel(const float *a, const float *b, int C, long HW, size_t total, const float *A,
+                                        const float *B, const float *Cc, float *out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / (size_t)HW) % (size_t)C);
+        float v = a[i] * A[c] + Cc[c];
+        if (b) v += b[i] * B[c];
+        out[i] = v;
+    }
+}
+
 // folded gradient -> bf16 T layout (layers without GDN between two convolutions)
 static __global__ void fold_to_bf16_kernel(FoldSrc f, __bf16 *out, int N, int C) {
     const size_t total = (size_t)N * f.H * f.W * C;

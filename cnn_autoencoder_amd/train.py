@@ -20,8 +20,9 @@ What the reference's training step does (``src/train_cae_ms.py:189-262``) and wh
 
 Variants covered: ``act_layer_type in (None, 'GDN', 'LeakyReLU', 'ReLU')`` units (the last two with their stride-1
 pre-convolutions) on the fused track functions, and residual units (``use_residual=True``) composed per operation from
-the same kernels (``_residual_track``); batch norm in training mode, groups, dropout and multiscale colour layers raise
-``NotImplementedError`` under autograd.
+the same kernels (``_composed_track``), as are units with batch norm in training mode (batch statistics, running
+statistics updated as ``nn.BatchNorm2d`` does); groups, dropout and multiscale colour layers raise ``NotImplementedError``
+under autograd.
 """
 from __future__ import annotations
 
@@ -529,9 +530,9 @@ class SynthesisFn(torch.autograd.Function):
 
 
 # ---- residual units (ResidualDownsamplingUnit / ResidualUpsamplingUnit, _autoencoders.py:104-174, :230-304) ----------
-# Their tracks are composed per operation, on NCHW fp32 tensors between operations: every convolution and every GDN is
-# one of the kernels above behind a small autograd function of its own, the residual sum and the LeakyReLU / ReLU in
-# front of the strided layer are element-wise torch operations on the unit's tensors.  (The canonical tracks keep their
+# and units with batch norm: their tracks are composed per operation, on NCHW fp32 tensors between operations: every
+# convolution, GDN and batch norm is one of the kernels behind a small autograd function of its own, the residual sum and
+# stand-alone LeakyReLU / ReLU modules are element-wise torch operations on the unit's tensors.  (The canonical tracks keep their
 # fused functions above; this form pays two layout conversions per operation.)
 
 class _ConvS1Fn(torch.autograd.Function):
@@ -667,38 +668,118 @@ def _torch_act(t: torch.Tensor, act: int) -> torch.Tensor:
     return t if not act else (torch.nn.functional.leaky_relu(t, 0.01) if act == 1 else torch.relu(t))
 
 
-def _residual_track(units, x: torch.Tensor, synthesis: bool) -> torch.Tensor:
-    """y = model(res_model(x) + x) per unit (_autoencoders.py:168-174, :298-304)."""
+class _BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm2d in training mode on an NCHW fp32 tensor: batch statistics (biased variance for the normalisation, as
+    torch) by cae_t_bn_moments, y = x w rstd + (b - mean w rstd) by cae_t_bn_affine; the backward is the same pair of kernels
+    with dy (the per-channel coefficients are C-element float64 arithmetic).  -> (y, batch mean, biased batch variance)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        L = _L()
+        x = x.detach().float().contiguous()
+        n, c, h, w = x.shape
+        dev = x.device
+        s1 = torch.empty(c, dtype=torch.float64, device=dev)
+        s2 = torch.empty(c, dtype=torch.float64, device=dev)
+        _lib.check(L.cae_t_bn_moments(x.data_ptr(), x.data_ptr(), n, c, h * w, s1.data_ptr(), s2.data_ptr(), _st()))
+        m = float(n * h * w)
+        mean = s1 / m
+        var = (s2 / m - mean * mean).clamp_min(0.0)
+        rstd = torch.rsqrt(var + eps)
+        wt = weight.detach().double() if weight is not None else torch.ones(c, dtype=torch.float64, device=dev)
+        bs = bias.detach().double() if bias is not None else torch.zeros(c, dtype=torch.float64, device=dev)
+        A = (wt * rstd).float().contiguous()
+        C = (bs - mean * wt * rstd).float().contiguous()
+        y = torch.empty_like(x)
+        _lib.check(L.cae_t_bn_affine(x.data_ptr(), None, n, c, h * w, A.data_ptr(), None, C.data_ptr(), y.data_ptr(), _st()))
+        ctx.x, ctx.stats, ctx.has = x, (mean, rstd, wt, m), (weight is not None, bias is not None)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _gm, _gv):
+        L = _L()
+        x = ctx.x
+        mean, rstd, wt, m = ctx.stats
+        n, c, h, w = x.shape
+        dev = x.device
+        dy = dy.detach().float().contiguous()
+        s1 = torch.empty(c, dtype=torch.float64, device=dev)
+        s2 = torch.empty(c, dtype=torch.float64, device=dev)
+        _lib.check(L.cae_t_bn_moments(dy.data_ptr(), x.data_ptr(), n, c, h * w, s1.data_ptr(), s2.data_ptr(), _st()))
+        sdyx = (s2 - mean * s1) * rstd  # sum dy xhat
+        # dx = w rstd (dy - sum(dy) / m - xhat sum(dy xhat) / m),  xhat = (x - mean) rstd
+        A = (wt * rstd).float().contiguous()
+        B = (-wt * rstd * rstd * sdyx / m).float().contiguous()
+        C = (wt * rstd * (-s1 / m + mean * rstd * sdyx / m)).float().contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(L.cae_t_bn_affine(dy.data_ptr(), x.data_ptr(), n, c, h * w, A.data_ptr(), B.data_ptr(), C.data_ptr(),
+                                     dx.data_ptr(), _st()))
+        has_w, has_b = ctx.has
+        return dx, (sdyx.float() if has_w else None), (s1.float() if has_b else None), None
+
+
+def _batch_norm(bn: nn.BatchNorm2d, x: torch.Tensor) -> torch.Tensor:
+    """bn(x) in training mode, with the running statistics updated as nn.BatchNorm2d does (unbiased variance, momentum or
+    the cumulative average when momentum is None)."""
+    y, mean, var = _BatchNormFn.apply(x, bn.weight, bn.bias, bn.eps)
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            cnt = x.numel() / x.shape[1]
+            bn.running_mean.mul_(1.0 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_((var * (cnt / max(cnt - 1.0, 1.0))).to(bn.running_var.dtype), alpha=mom)
+    return y
+
+
+def _run_sequence(u, seq, x: torch.Tensor, synthesis: bool) -> torch.Tensor:
+    """The modules of a unit's nn.Sequential, one operation each (the module order IS the reference's forward)."""
+    from .modules import GDN, _ConvParams
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, _ConvParams):
+            if m.groups != 1:
+                raise NotImplementedError('training with grouped layers is not built')
+            if m is u.main:  # the strided layer
+                if synthesis:
+                    spec = LayerSpec(m.in_channels, m.out_channels, m.kernel_size, m.bias is not None, False)
+                    x = SynthesisFn.apply(x, (spec,), *([m.weight] + ([m.bias] if m.bias is not None else [])))
+                else:
+                    x = _ConvS2Fn.apply(x, m.kernel_size, m.weight, m.bias)
+            else:  # stride 1; a LeakyReLU / ReLU right behind it rides in the kernel's epilogue
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                act = 1 if isinstance(nxt, nn.LeakyReLU) else (2 if isinstance(nxt, nn.ReLU) else 0)
+                x = _ConvS1Fn.apply(x, synthesis, m.kernel_size, act, m.weight, m.bias)
+                i += 1 if act else 0
+        elif isinstance(m, nn.BatchNorm2d):
+            x = _batch_norm(m, x) if m.training else m(x)
+        elif isinstance(m, GDN):
+            x = _GdnFn.apply(x, m.inverse, *_gdn_params(m, m.in_channels))
+        elif isinstance(m, nn.LeakyReLU):
+            x = torch.nn.functional.leaky_relu(x, m.negative_slope)
+        elif isinstance(m, nn.ReLU):
+            x = torch.relu(x)
+        elif isinstance(m, nn.Dropout2d):
+            if m.p > 0 and m.training:
+                raise NotImplementedError('training with Dropout2d is not built')
+        elif not isinstance(m, nn.Identity):
+            raise NotImplementedError(f'{type(m).__name__} is not part of the compression path')
+        i += 1
+    return x
+
+
+def _composed_track(units, x: torch.Tensor, synthesis: bool) -> torch.Tensor:
+    """Tracks with residual units (y = model(res_model(x) + x), _autoencoders.py:168-174, :298-304) or batch norm:
+    composed per operation."""
+    from .modules import _ResidualUnit
     for u in units:
-        convs = [u.res_model[ci] for ci, _, _ in u._res] + [u.main]
-        if u.main_bn_index is not None or any(bi is not None for _, bi, _ in u._res) or any(cv.groups != 1 for cv in convs):
-            raise NotImplementedError('training with BatchNorm or grouped layers is not built')
-        if any(isinstance(m, nn.Dropout2d) and m.p > 0 for m in u.model):
-            raise NotImplementedError('training with Dropout2d is not built')
-        cin = u.main.in_channels
-        r = x
-        last = len(u._res) - 1
-        for k, (ci, _, gi) in enumerate(u._res):
-            conv = u.res_model[ci]
-            act = 0 if gi is not None else (u.act_code if (k == 0 or u._second_stage_act) else 0)
-            r = _ConvS1Fn.apply(r, synthesis, conv.kernel_size, act, conv.weight, conv.bias)
-            if gi is not None:
-                r = _GdnFn.apply(r, synthesis, *_gdn_params(u.res_model[gi], cin))
-        r = r + x
-        if last == 1:  # LeakyReLU / ReLU units: the activation in front of the strided layer
-            r = _torch_act(r, u.act_code)
-        conv = u.main
-        if synthesis:
-            spec = LayerSpec(conv.in_channels, conv.out_channels, conv.kernel_size, conv.bias is not None, False)
-            tensors = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
-            y = SynthesisFn.apply(r, (spec,), *tensors)
+        if isinstance(u, _ResidualUnit):
+            x = _run_sequence(u, u.model, _run_sequence(u, u.res_model, x, synthesis) + x, synthesis)
         else:
-            y = _ConvS2Fn.apply(r, conv.kernel_size, conv.weight, conv.bias)
-        if u.gdn is not None:
-            y = _GdnFn.apply(y, synthesis, *_gdn_params(u.gdn, conv.out_channels))
-        else:
-            y = _torch_act(y, u.act_code)
-        x = y
+            x = _run_sequence(u, u.model, x, synthesis)
     return x
 
 
@@ -709,10 +790,10 @@ def _track_inputs(track, units, synthesis: bool):
     if getattr(track, 'multiscale_analysis', False):
         raise NotImplementedError('training with multiscale colour layers is not built')
     for u in units:
-        if isinstance(u, _ResidualUnit):
-            return None, None  # composed per operation: _residual_track
-        if u.main_bn_index is not None or u.pre_bn_index is not None or u.main.groups != 1:
-            raise NotImplementedError('training with BatchNorm or grouped layers is not built')
+        if isinstance(u, _ResidualUnit) or u.main_bn_index is not None or u.pre_bn_index is not None:
+            return None, None  # composed per operation: _composed_track
+        if u.main.groups != 1:
+            raise NotImplementedError('training with grouped layers is not built')
         conv = u.main
         has_gdn = u.gdn is not None
         specs.append(LayerSpec(conv.in_channels, conv.out_channels, conv.kernel_size, conv.bias is not None, has_gdn,
@@ -750,7 +831,7 @@ def analysis_forward(track, x: torch.Tensor) -> torch.Tensor:
     specs, tensors = _track_inputs(track, track._units(), False)
     x = x.to(device=dev, dtype=torch.float32)
     if specs is None:
-        return _residual_track(track._units(), x, False)
+        return _composed_track(track._units(), x, False)
     return AnalysisFn.apply(x, specs, *tensors)
 
 
@@ -758,7 +839,7 @@ def synthesis_forward(track, yq: torch.Tensor):
     dev = _lib.require_gpu()
     specs, tensors = _track_inputs(track, track._units(), True)
     yq = yq.to(device=dev, dtype=torch.float32)
-    out = _residual_track(track._units(), yq, True) if specs is None else SynthesisFn.apply(yq, specs, *tensors)
+    out = _composed_track(track._units(), yq, True) if specs is None else SynthesisFn.apply(yq, specs, *tensors)
     L = len(track._units())
     # (x_r list, fx_brg) as the reference's Synthesizer; intermediate features are not materialised while training
     return [out] + [None] * (L - 1), [None] * (L - 1) + [out]

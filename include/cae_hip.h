@@ -329,6 +329,17 @@ int cae_t_gdn_forward_save(const float *z32, long pixels, int cp, const float *b
 int cae_t_gdn_backward_fused(const float *z32, const float *f_saved, float *gext32 /* folded in place */, int n, int h, int w, int pad, int cp,
                              const float *gamma, int inverse, void *gz16, float *ggamma, float *gbeta, void *stream);
 int cae_t_fold_to_bf16(const float *gext32, int n, int h, int w, int pad, int cp, void *out16, void *stream);
+
+/* nn.BatchNorm2d in TRAINING mode (batch statistics; the units' optional batch norm, _autoencoders.py:72-73, :87-88, and
+ * its backward as torch autograd derives it) on NCHW fp32 tensors (n, c, hw).  Both directions are a pair of per-channel
+ * moments and a per-channel affine map:
+ *   cae_t_bn_moments   s1[c] = sum a, s2[c] = sum a b   over (n, hw), accumulated in double
+ *                      (forward: a = b = x; backward: a = dy, b = x)
+ *   cae_t_bn_affine    out = a A[c] + (b ? b B[c] : 0) + C[c]
+ *                      (forward: y = x w rstd + (bias - mean w rstd); backward: dx = dy A + x B + C) */
+int cae_t_bn_moments(const float *a, const float *b, int n, int c, long hw, double *s1, double *s2, void *stream);
+int cae_t_bn_affine(const float *a, const float *b, int n, int c, long hw, const float *A, const float *B, const float *C,
+                    float *out, void *stream);
 int cae_t_colsum(const void *g16, long pixels, int cp, float *out, void *stream); /* bias gradient */
 
 /* Training-mode density of the entropy bottleneck, fused (csrc/cae_density_train.hip).  Replaces the element-wise graph of

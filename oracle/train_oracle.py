@@ -124,6 +124,13 @@ def synthesis(y: torch.Tensor, layers: Sequence[dict], bf16: bool = True, act: O
     return fx
 
 
+def _bn(x: torch.Tensor, bn: Optional[dict]) -> torch.Tensor:
+    """nn.BatchNorm2d in training mode (batch statistics): bn = {'weight', 'bias', 'eps'} or None"""
+    if bn is None:
+        return x
+    return F.batch_norm(x, None, None, bn.get('weight'), bn.get('bias'), True, 0.0, bn.get('eps', 1e-5))
+
+
 def residual_track(x: torch.Tensor, units: Sequence[dict], synthesis: bool, bf16: bool = True) -> torch.Tensor:
     """Residual units (ResidualDownsamplingUnit / ResidualUpsamplingUnit, _autoencoders.py:104-174, :230-304):
     y = model(res_model(x) + x).  units[i] = {'stages': [{'weight', 'bias'?, 'beta'?, 'gamma'?, 'act'?}], 'post_act'?,
@@ -131,7 +138,9 @@ def residual_track(x: torch.Tensor, units: Sequence[dict], synthesis: bool, bf16
     synthesis: ConvTranspose2d(stride 1, padding k//2)) each followed by GDN / IGDN or an activation, model = [activation]
     + the strided layer + GDN / IGDN or activation.  Rounding points of the HIP path (`bf16`): operands of every convolution,
     the gradient at every convolution's output, the output of every GDN, and the gradient an analysis-side convolution hands to
-    its input (folded from the extended domain into bf16)."""
+    its input (folded from the extended domain into bf16).  Optional 'bn' entries ({'weight', 'bias', 'eps'}) behind a
+    convolution: BatchNorm2d with batch statistics (:72-73, :87-88); units with 'residual': False are the plain
+    DownsamplingUnit / UpsamplingUnit (their stride-1 pre-convolution as the one stage, no residual sum)."""
     fx = x
     for U in units:
         r = fx
@@ -142,18 +151,20 @@ def residual_track(x: torch.Tensor, units: Sequence[dict], synthesis: bool, bf16
                 u = F.conv_transpose2d(rin, _r(S['weight'], bf16), S.get('bias'), stride=1, padding=k // 2)
             else:
                 u = F.conv2d(F.pad(rin, (k // 2,) * 4, mode='reflect'), _r(S['weight'], bf16), S.get('bias'))
-            u = _g(u, bf16)
+            u = _bn(_g(u, bf16), S.get('bn'))
             if S.get('beta') is not None:
-                r = _r(gdn(u, S['beta'], S['gamma'], synthesis), bf16)
+                r = _r(gdn(_g(u, bf16), S['beta'], S['gamma'], synthesis), bf16)  # (the GDN backward kernel emits bf16)
             else:
                 r = _act(u, S.get('act'))
-        r = _act(r + fx, U.get('post_act'))
+        if U.get('residual', True):
+            r = _act(r + fx, U.get('post_act'))
         if synthesis:
             y = _g(O.deconv_s2(_r(r, bf16), _r(U['weight'], bf16), U.get('bias')), bf16)
         else:
             y = _g(O.reflect_conv_s2(_r(_g(r, bf16), bf16), _r(U['weight'], bf16), U.get('bias')), bf16)
+        y = _bn(y, U.get('bn'))
         if U.get('beta') is not None:
-            y = _r(gdn(y, U['beta'], U['gamma'], synthesis), bf16)
+            y = _r(gdn(_g(y, bf16), U['beta'], U['gamma'], synthesis), bf16)
         else:
             y = _act(y, U.get('act'))
         fx = y

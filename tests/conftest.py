@@ -68,7 +68,9 @@ def built_lib():
 
 
 def residual_oracle_units(track, act_name):
-    """(oracle unit dicts with leaf clones, [(module parameter name, leaf)]) of a residual track"""
+    """(oracle unit dicts with leaf clones for oracle.train_oracle.residual_track, [(module parameter name, leaf)]) of a track of
+    residual units, or of plain units (their stride-1 pre-convolution as the one stage, 'residual': False); batch norms as
+    'bn' entries"""
     units, pairs = [], []
 
     def leaf(p, name):
@@ -77,20 +79,37 @@ def residual_oracle_units(track, act_name):
         t = p.detach().cpu().clone().requires_grad_(True)
         pairs.append((name, t))
         return t
+
+    def bn(seq, idx, prefix):
+        if idx is None:
+            return None
+        m = seq[idx]
+        return dict(weight=leaf(m.weight, f'{prefix}.{idx}.weight'), bias=leaf(m.bias, f'{prefix}.{idx}.bias'), eps=m.eps)
     for i, u in enumerate(track):
         stages = []
-        for k, (ci, _, gi) in enumerate(u._res):
-            conv = u.res_model[ci]
-            d = dict(weight=leaf(conv.weight, f'{i}.res_model.{ci}.weight'), bias=leaf(conv.bias, f'{i}.res_model.{ci}.bias'))
-            if gi is not None:
-                g = u.res_model[gi]
-                d.update(beta=leaf(g.beta, f'{i}.res_model.{gi}.beta'), gamma=leaf(g.gamma, f'{i}.res_model.{gi}.gamma'))
-            else:
-                d['act'] = act_name if (u.act_code and (k == 0 or u._second_stage_act)) else None
-            stages.append(d)
+        residual = hasattr(u, '_res')
+        if residual:
+            for k, (ci, bi, gi) in enumerate(u._res):
+                conv = u.res_model[ci]
+                d = dict(weight=leaf(conv.weight, f'{i}.res_model.{ci}.weight'), bias=leaf(conv.bias, f'{i}.res_model.{ci}.bias'),
+                         bn=bn(u.res_model, bi, f'{i}.res_model'))
+                if gi is not None:
+                    g = u.res_model[gi]
+                    d.update(beta=leaf(g.beta, f'{i}.res_model.{gi}.beta'), gamma=leaf(g.gamma, f'{i}.res_model.{gi}.gamma'))
+                else:
+                    d['act'] = act_name if (u.act_code and (k == 0 or u._second_stage_act)) else None
+                stages.append(d)
+            post_act = act_name if (u.act_code and len(u._res) == 2) else None
+        else:
+            if u.pre is not None:
+                pi = u.pre_index
+                stages.append(dict(weight=leaf(u.pre.weight, f'{i}.model.{pi}.weight'), bias=leaf(u.pre.bias, f'{i}.model.{pi}.bias'),
+                                   bn=bn(u.model, u.pre_bn_index, f'{i}.model'), act=act_name))
+            post_act = None
         mi = u.main_index
-        d = dict(stages=stages, post_act=act_name if (u.act_code and len(u._res) == 2) else None,
-                 weight=leaf(u.main.weight, f'{i}.model.{mi}.weight'), bias=leaf(u.main.bias, f'{i}.model.{mi}.bias'))
+        d = dict(stages=stages, post_act=post_act, residual=residual,
+                 weight=leaf(u.main.weight, f'{i}.model.{mi}.weight'), bias=leaf(u.main.bias, f'{i}.model.{mi}.bias'),
+                 bn=bn(u.model, u.main_bn_index, f'{i}.model'))
         if u.gdn is not None:
             d.update(beta=leaf(u.gdn.beta, f'{i}.model.{u.gdn_index}.beta'), gamma=leaf(u.gdn.gamma, f'{i}.model.{u.gdn_index}.gamma'))
         else:

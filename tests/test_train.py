@@ -397,6 +397,62 @@ def test_twenty_training_steps_follow_the_restatement(cae):
     assert rel(eb.quantiles.detach().cpu(), eb_ref['quantiles'].detach()) < 1e-3
 
 
+@pytest.mark.parametrize('residual,act', [(False, 'LeakyReLU'), (False, 'GDN'), (True, 'ReLU')])
+def test_batch_norm_units_train_on_batch_statistics(cae, residual, act):
+    """nn.BatchNorm2d in training mode inside the units (_autoencoders.py:72-73, :87-88): outputs and every gradient (batch-norm
+    affine parameters included) against torch-CPU autograd with F.batch_norm(training=True); running statistics updated as
+    nn.BatchNorm2d does."""
+    from conftest import residual_oracle_units
+    from oracle import train_oracle as T
+    torch.manual_seed(13)
+    kw = dict(channels_org=3, channels_net=32, channels_bn=48, compression_level=2, bias=True, batch_norm=True,
+              use_residual=residual, act_layer_type=act)
+    enc, dec = cae.Analyzer(**kw).cuda().train(), cae.Synthesizer(**kw).cuda().train()
+    with torch.no_grad():
+        for mod in list(enc.modules()) + list(dec.modules()):
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.2, 0.2)
+    act_name = act if act in ('LeakyReLU', 'ReLU') else None
+    for name, mod, track, inp, synthesis in (('analysis', enc, enc.analysis_track, torch.rand(4, 3, 40, 56), False),
+                                             ('synthesis', dec, dec.synthesis_track, 2.0 * torch.randn(4, 48, 5, 7), True)):
+        units, pairs = residual_oracle_units(track, act_name)
+        xin = inp.clone().requires_grad_(True)
+        ref = T.residual_track(xin, units, synthesis, bf16=True)
+        bns = [m for m in mod.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        assert bns and all(float(m.num_batches_tracked) == 0 for m in bns)
+        xdev = inp.cuda().requires_grad_(True)
+        out = mod(xdev)
+        out = out[0][0] if synthesis else out
+        g = torch.randn_like(ref.detach())
+        ref.backward(g)
+        out.backward(g.cuda())
+        scale = max(1.0, float(ref.detach().abs().max()))
+        assert float((out.detach().cpu() - ref.detach()).abs().max()) / scale < 2e-3, name
+        if synthesis:
+            assert rel(xdev.grad, xin.grad) < 2.5e-3, name
+        got = {n: p.grad.detach().cpu() for n, p in mod.named_parameters() if p.grad is not None}
+        prefix = 'synthesis_track.' if synthesis else 'analysis_track.'
+        assert len(got) == len(pairs), (sorted(got), [n for n, _ in pairs])
+        # Parameters whose true gradient is ZERO hold rounding noise on both sides: a bias in front of a batch norm (the batch
+        # mean is subtracted again), and any per-channel shift in front of a reflect-padded convolution + batch norm (a constant
+        # stays constant under reflect padding).  Such parameters are recognised by their size against the track's largest gradient.
+        # (relative part: measured up to 3.1e-3 -- bf16 rounding flips as in the other gradient tests, one more normalisation)
+        gmax = max(float(leaf.grad.abs().max()) for _, leaf in pairs)
+        pre_bn = {id(d['bias']): float(d['weight'].grad.abs().max()) for U in units for d in U['stages'] + [U]
+                  if d.get('bn') is not None and d.get('bias') is not None}
+        for pname, leaf in pairs:
+            if id(leaf) in pre_bn:  # bias in front of a batch norm: sums of rounding errors on both sides
+                assert float(got[prefix + pname].abs().max()) < 1e-2 * pre_bn[id(leaf)], (name, pname)
+                assert float(leaf.grad.abs().max()) < 1e-2 * pre_bn[id(leaf)], (name, pname)
+            elif float(leaf.grad.abs().max()) < 3e-3 * gmax:  # noise around zero on the restatement's side: noise here too
+                assert float(got[prefix + pname].abs().max()) < 1e-2 * gmax, (name, pname)
+            else:
+                assert rel(got[prefix + pname], leaf.grad) < 5e-3, (name, pname)
+        # running statistics moved off their initial values (0 / 1) by one momentum step
+        assert all(float(m.num_batches_tracked) == 1 and float(m.running_mean.abs().max()) > 0 for m in bns)
+
+
 def test_training_steps_of_a_residual_model(cae):
     """train.train_step on a residual GDN model (use_residual=True): every parameter of both tracks receives a gradient and
     the rate-distortion loss falls over a few steps on a fixed batch."""
