@@ -21,8 +21,8 @@ What the reference's training step does (``src/train_cae_ms.py:189-262``) and wh
 Variants covered: ``act_layer_type in (None, 'GDN', 'LeakyReLU', 'ReLU')`` units (the last two with their stride-1
 pre-convolutions) on the fused track functions, and residual units (``use_residual=True``) composed per operation from
 the same kernels (``_composed_track``), as are units with batch norm in training mode (batch statistics, running
-statistics updated as ``nn.BatchNorm2d`` does); groups, dropout and multiscale colour layers raise ``NotImplementedError``
-under autograd.
+statistics updated as ``nn.BatchNorm2d`` does), grouped layers (dense kernels on the block-diagonal embedding of the
+grouped weight) and ``Dropout2d``; multiscale colour layers raise ``NotImplementedError`` under autograd.
 """
 from __future__ import annotations
 
@@ -733,6 +733,27 @@ def _batch_norm(bn: nn.BatchNorm2d, x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def _dense_weight(m) -> torch.Tensor:
+    """The dense (groups = 1) weight of a grouped layer as a differentiable function of its parameter: block-diagonal
+    embedding by one index_put (modules._ConvParams.dense_weight is its no-grad twin for the inference upload); the
+    gradient of the grouped weight is the block diagonal of the dense kernels' weight gradient."""
+    w = m.weight
+    if m.groups == 1:
+        return w
+    g, k = m.groups, m.kernel_size
+    cin_g, cout_g = m.in_channels // g, m.out_channels // g
+    dev = w.device
+    if m.transposed:  # (cin, cout_g, k, k) -> (cin, cout, k, k)
+        rows = torch.arange(m.in_channels, device=dev)
+        cols = (rows // cin_g)[:, None] * cout_g + torch.arange(cout_g, device=dev)[None, :]
+        dense = w.new_zeros(m.in_channels, m.out_channels, k, k)
+    else:             # (cout, cin_g, k, k) -> (cout, cin, k, k)
+        rows = torch.arange(m.out_channels, device=dev)
+        cols = (rows // cout_g)[:, None] * cin_g + torch.arange(cin_g, device=dev)[None, :]
+        dense = w.new_zeros(m.out_channels, m.in_channels, k, k)
+    return dense.index_put((rows[:, None].expand_as(cols), cols), w)
+
+
 def _run_sequence(u, seq, x: torch.Tensor, synthesis: bool) -> torch.Tensor:
     """The modules of a unit's nn.Sequential, one operation each (the module order IS the reference's forward)."""
     from .modules import GDN, _ConvParams
@@ -741,18 +762,17 @@ def _run_sequence(u, seq, x: torch.Tensor, synthesis: bool) -> torch.Tensor:
     while i < len(mods):
         m = mods[i]
         if isinstance(m, _ConvParams):
-            if m.groups != 1:
-                raise NotImplementedError('training with grouped layers is not built')
+            wd = _dense_weight(m)  # (grouped layers: the dense kernels on the block-diagonal embedding)
             if m is u.main:  # the strided layer
                 if synthesis:
                     spec = LayerSpec(m.in_channels, m.out_channels, m.kernel_size, m.bias is not None, False)
-                    x = SynthesisFn.apply(x, (spec,), *([m.weight] + ([m.bias] if m.bias is not None else [])))
+                    x = SynthesisFn.apply(x, (spec,), *([wd] + ([m.bias] if m.bias is not None else [])))
                 else:
-                    x = _ConvS2Fn.apply(x, m.kernel_size, m.weight, m.bias)
+                    x = _ConvS2Fn.apply(x, m.kernel_size, wd, m.bias)
             else:  # stride 1; a LeakyReLU / ReLU right behind it rides in the kernel's epilogue
                 nxt = mods[i + 1] if i + 1 < len(mods) else None
                 act = 1 if isinstance(nxt, nn.LeakyReLU) else (2 if isinstance(nxt, nn.ReLU) else 0)
-                x = _ConvS1Fn.apply(x, synthesis, m.kernel_size, act, m.weight, m.bias)
+                x = _ConvS1Fn.apply(x, synthesis, m.kernel_size, act, wd, m.bias)
                 i += 1 if act else 0
         elif isinstance(m, nn.BatchNorm2d):
             x = _batch_norm(m, x) if m.training else m(x)
@@ -763,8 +783,7 @@ def _run_sequence(u, seq, x: torch.Tensor, synthesis: bool) -> torch.Tensor:
         elif isinstance(m, nn.ReLU):
             x = torch.relu(x)
         elif isinstance(m, nn.Dropout2d):
-            if m.p > 0 and m.training:
-                raise NotImplementedError('training with Dropout2d is not built')
+            x = m(x)  # (channel mask from torch's generator, as in the reference; the identity in eval mode)
         elif not isinstance(m, nn.Identity):
             raise NotImplementedError(f'{type(m).__name__} is not part of the compression path')
         i += 1
@@ -790,10 +809,9 @@ def _track_inputs(track, units, synthesis: bool):
     if getattr(track, 'multiscale_analysis', False):
         raise NotImplementedError('training with multiscale colour layers is not built')
     for u in units:
-        if isinstance(u, _ResidualUnit) or u.main_bn_index is not None or u.pre_bn_index is not None:
+        if (isinstance(u, _ResidualUnit) or u.main_bn_index is not None or u.pre_bn_index is not None or u.main.groups != 1
+                or any(isinstance(m, nn.Dropout2d) and m.p > 0 for m in u.model)):
             return None, None  # composed per operation: _composed_track
-        if u.main.groups != 1:
-            raise NotImplementedError('training with grouped layers is not built')
         conv = u.main
         has_gdn = u.gdn is not None
         specs.append(LayerSpec(conv.in_channels, conv.out_channels, conv.kernel_size, conv.bias is not None, has_gdn,

@@ -80,6 +80,22 @@ def residual_oracle_units(track, act_name):
         pairs.append((name, t))
         return t
 
+    def wleaf(conv, name):
+        """weight leaf; a grouped layer enters the restatement through its dense block-diagonal embedding (differentiable)"""
+        t = leaf(conv.weight, name)
+        if conv.groups == 1:
+            return t
+        import torch
+        g, k = conv.groups, conv.kernel_size
+        cin_g, cout_g = conv.in_channels // g, conv.out_channels // g
+        if conv.transposed:
+            dense = [torch.cat([t[ci:ci + 1] if (ci // cin_g) == j else torch.zeros(1, cout_g, k, k) for j in range(g)], dim=1)
+                     for ci in range(conv.in_channels)]
+        else:
+            dense = [torch.cat([t[co:co + 1] if (co // cout_g) == j else torch.zeros(1, cin_g, k, k) for j in range(g)], dim=1)
+                     for co in range(conv.out_channels)]
+        return torch.cat(dense, dim=0)
+
     def bn(seq, idx, prefix):
         if idx is None:
             return None
@@ -91,7 +107,7 @@ def residual_oracle_units(track, act_name):
         if residual:
             for k, (ci, bi, gi) in enumerate(u._res):
                 conv = u.res_model[ci]
-                d = dict(weight=leaf(conv.weight, f'{i}.res_model.{ci}.weight'), bias=leaf(conv.bias, f'{i}.res_model.{ci}.bias'),
+                d = dict(weight=wleaf(conv, f'{i}.res_model.{ci}.weight'), bias=leaf(conv.bias, f'{i}.res_model.{ci}.bias'),
                          bn=bn(u.res_model, bi, f'{i}.res_model'))
                 if gi is not None:
                     g = u.res_model[gi]
@@ -103,12 +119,12 @@ def residual_oracle_units(track, act_name):
         else:
             if u.pre is not None:
                 pi = u.pre_index
-                stages.append(dict(weight=leaf(u.pre.weight, f'{i}.model.{pi}.weight'), bias=leaf(u.pre.bias, f'{i}.model.{pi}.bias'),
+                stages.append(dict(weight=wleaf(u.pre, f'{i}.model.{pi}.weight'), bias=leaf(u.pre.bias, f'{i}.model.{pi}.bias'),
                                    bn=bn(u.model, u.pre_bn_index, f'{i}.model'), act=act_name))
             post_act = None
         mi = u.main_index
         d = dict(stages=stages, post_act=post_act, residual=residual,
-                 weight=leaf(u.main.weight, f'{i}.model.{mi}.weight'), bias=leaf(u.main.bias, f'{i}.model.{mi}.bias'),
+                 weight=wleaf(u.main, f'{i}.model.{mi}.weight'), bias=leaf(u.main.bias, f'{i}.model.{mi}.bias'),
                  bn=bn(u.model, u.main_bn_index, f'{i}.model'))
         if u.gdn is not None:
             d.update(beta=leaf(u.gdn.beta, f'{i}.model.{u.gdn_index}.beta'), gamma=leaf(u.gdn.gamma, f'{i}.model.{u.gdn_index}.gamma'))

@@ -453,6 +453,39 @@ def test_batch_norm_units_train_on_batch_statistics(cae, residual, act):
         assert all(float(m.num_batches_tracked) == 1 and float(m.running_mean.abs().max()) > 0 for m in bns)
 
 
+@pytest.mark.parametrize('act,residual', [('ReLU', False), ('GDN', True)])
+def test_grouped_layers_train(cae, act, residual):
+    """groups=True (depthwise layers, groups = channels_in; _autoencoders.py:64-66, :79-81): the dense kernels run on the
+    block-diagonal embedding of the grouped weight, its gradient is the block diagonal of theirs -- against torch-CPU autograd of
+    the restatement on the same embedding (that the embedding equals the grouped layer is pinned by the var_groups_* fixtures)."""
+    from conftest import residual_oracle_units
+    from oracle import train_oracle as T
+    torch.manual_seed(17)
+    act_name = act if act in ('LeakyReLU', 'ReLU') else None
+    common = dict(compression_level=2, bias=True, groups=True, use_residual=residual, act_layer_type=act)
+    enc = cae.Analyzer(channels_org=4, channels_net=8, channels_bn=16, **common).cuda().train()
+    dec = cae.Synthesizer(channels_org=8, channels_net=8, channels_bn=8, **common).cuda().train()
+    for name, mod, track, inp, synthesis in (('analysis', enc, enc.analysis_track, torch.rand(2, 4, 40, 56), False),
+                                             ('synthesis', dec, dec.synthesis_track, 2.0 * torch.randn(2, 8, 5, 7), True)):
+        units, pairs = residual_oracle_units(track, act_name)
+        assert any(l.shape[1] == 1 for _, l in pairs if l.dim() == 4)  # depthwise parameters
+        xin = inp.clone().requires_grad_(True)
+        ref = T.residual_track(xin, units, synthesis, bf16=True)
+        xdev = inp.cuda().requires_grad_(True)
+        out = mod(xdev)
+        out = out[0][0] if synthesis else out
+        g = torch.randn_like(ref.detach())
+        ref.backward(g)
+        out.backward(g.cuda())
+        scale = max(1.0, float(ref.detach().abs().max()))
+        assert float((out.detach().cpu() - ref.detach()).abs().max()) / scale < 2e-3, name
+        got = {n: p.grad.detach().cpu() for n, p in mod.named_parameters() if p.grad is not None}
+        prefix = 'synthesis_track.' if synthesis else 'analysis_track.'
+        assert len(got) == len(pairs)
+        for pname, leaf in pairs:
+            assert got[prefix + pname].shape == leaf.shape and rel(got[prefix + pname], leaf.grad) < 2.5e-3, (name, pname)
+
+
 def test_training_steps_of_a_residual_model(cae):
     """train.train_step on a residual GDN model (use_residual=True): every parameter of both tracks receives a gradient and
     the rate-distortion loss falls over a few steps on a fixed batch."""
