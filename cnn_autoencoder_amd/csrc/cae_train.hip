@@ -459,7 +459,7 @@ int cae_t_im2col_s2(const float *x_nchw, int n, int c, int h, int w, int oh, int
     if (!x_nchw || !out16) return fail(CAE_ERR_ARG, "NULL argument");
     if (n < 1 || c < 1 || h < 1 || w < 1 || oh < 1 || ow < 1 || (ks != 3 && ks != 5) || ks * ks * c > 32)
         return fail(CAE_ERR_ARG, "bad shape (kernel_size^2 * channels must fit 32)");
-    hipLaunchKernelGGL(im2col_s2_kernel, dim3(ew_grid((size_t)n * oh * ow * 32)), dim3(256), 0, (hipStream_t)stream, x_nchw,
+    hipLaunchKernelGGL(im2col_s2_kernel, dim3(ew_grid((size_t)n * oh * ow * 4)), dim3(256), 0, (hipStream_t)stream, x_nchw,
                        (__bf16 *)out16, n, c, h, w, oh, ow, ks, reflect);
     HIP_TRY(hipGetLastError());
     return CAE_OK;
@@ -469,7 +469,7 @@ int cae_t_col2im_s2(const float *u32, const float *bias, int n, int c, int h, in
     if (!u32 || !out_nchw) return fail(CAE_ERR_ARG, "NULL argument");
     if (n < 1 || c < 1 || h < 1 || w < 1 || (ks != 3 && ks != 5) || ks * ks * c > 32)
         return fail(CAE_ERR_ARG, "bad shape (kernel_size^2 * channels must fit 32)");
-    hipLaunchKernelGGL(col2im_s2_kernel, dim3(ew_grid((size_t)n * c * 4 * h * w)), dim3(256), 0, (hipStream_t)stream, u32, bias,
+    hipLaunchKernelGGL(col2im_s2_kernel, dim3(ew_grid((size_t)n * 4 * h * w)), dim3(256), 0, (hipStream_t)stream, u32, bias,
                        out_nchw, n, c, h, w, ks);
     HIP_TRY(hipGetLastError());
     return CAE_OK;

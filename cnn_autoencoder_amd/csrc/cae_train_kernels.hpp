@@ -1083,57 +1083,70 @@ __global__ void __launch_bounds__(CT * 64, 1) gdn_gemm_b_kernel(const float *gn,
 // gather-GEMM / weight gradient on it, and for the last layer's forward the transposed form: per INPUT position the 27
 // products u[pos][(tap, co)], then col2im sums the <= 4 terms of every output pixel into NCHW fp32.
 // ---------------------------------------------------------------------------------------------------------------
+// One thread per (position, 16-byte quarter of its record): eight values gathered, one 16-byte store -- consecutive threads
+// write consecutive pieces.  (The element-per-thread form spent its time on 64-bit index arithmetic and 2-byte stores:
+// 0.20 ms per 128 x 3 x 256^2 image batch, now a quarter of that.)
 static __global__ void im2col_s2_kernel(const float *x, __bf16 *out, int N, int C, int H, int W, int OH, int OW, int ks,
                                         int reflect) {
-    const size_t total = (size_t)N * OH * OW * 32;
+    const size_t total = (size_t)N * OH * OW * 4;
     const int P = ks / 2, K = ks * ks * C;
+    const size_t plane = (size_t)H * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 31);
-        size_t r = i >> 5;
+        const int q = (int)(i & 3);
+        size_t r = i >> 2;
         const int ox = (int)(r % OW);
         r /= OW;
         const int oy = (int)(r % OH);
         const int n = (int)(r / OH);
-        float v = 0.0f;
-        if (j < K) {
-            const int tap = j / C, c = j - tap * C;
-            int iy = 2 * oy + tap / ks - P, ix = 2 * ox + tap % ks - P;
-            bool ok = true;
-            if (reflect) {
-                iy = reflect_idx(iy, H);
-                ix = reflect_idx(ix, W);
-            } else {
-                ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float *xn = x + (size_t)n * C * plane;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = 8 * q + e;
+            float f = 0.0f;
+            if (j < K) {
+                const int tap = j / C, c = j - tap * C;
+                const int ky = tap / ks, kx = tap - ky * ks;
+                int iy = 2 * oy + ky - P, ix = 2 * ox + kx - P;
+                bool ok = true;
+                if (reflect) {
+                    iy = reflect_idx(iy, H);
+                    ix = reflect_idx(ix, W);
+                } else {
+                    ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                }
+                if (ok) f = xn[(size_t)c * plane + (size_t)iy * W + ix];
             }
-            if (ok) v = x[((size_t)n * C + c) * H * W + (size_t)iy * W + ix];
+            v[e] = (__bf16)f;
         }
-        out[i] = (__bf16)v;
+        *(bf16x8 *)(out + i * 8) = v;
     }
 }
 
 // out[n][c][Y][X] = bias[c] + sum over taps (ky, kx) with (Y + P - ky), (X + P - kx) even and inside of
 // u[n][(Y + P - ky) / 2][(X + P - kx) / 2][(ky * ks + kx) * C + c]      (ConvTranspose2d(k, stride 2, padding k//2, output_padding 1))
+// One thread per output PIXEL, all its channels (C <= 3 for k = 3): the <= 4 (k = 3) or <= 9 (k = 5) terms of a pixel share their
+// index arithmetic and read C adjacent floats of each record.
 static __global__ void col2im_s2_kernel(const float *u, const float *bias, float *out, int N, int C, int H, int W, int ks) {
     const int OH = 2 * H, OW = 2 * W, P = ks / 2;
-    const size_t total = (size_t)N * C * OH * OW;
+    const size_t total = (size_t)N * OH * OW, oplane = (size_t)OH * OW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int X = (int)(i % OW);
         size_t r = i / OW;
         const int Y = (int)(r % OH);
-        r /= OH;
-        const int c = (int)(r % C);
-        const int n = (int)(r / C);
-        float s = bias ? bias[c] : 0.0f;
+        const int n = (int)(r / OH);
+        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // (C <= 3 when ks * ks * C <= 32 and ks >= 3)
         for (int ky = (Y + P) & 1; ky < ks; ky += 2) {
             const int iy = (Y + P - ky) >> 1;
             if (iy < 0 || iy >= H || Y + P - ky < 0) continue;
             for (int kx = (X + P) & 1; kx < ks; kx += 2) {
                 const int ix = (X + P - kx) >> 1;
                 if (ix < 0 || ix >= W || X + P - kx < 0) continue;
-                s += u[(((size_t)n * H + iy) * W + ix) * 32 + (ky * ks + kx) * C + c];
+                const float *rec = u + (((size_t)n * H + iy) * W + ix) * 32 + (ky * ks + kx) * C;
+                for (int c = 0; c < C; ++c) s[c] += rec[c];
             }
         }
-        out[i] = s;
+        for (int c = 0; c < C; ++c) out[((size_t)n * C + c) * oplane + (size_t)Y * OW + X] = s[c] + (bias ? bias[c] : 0.0f);
     }
 }
 
