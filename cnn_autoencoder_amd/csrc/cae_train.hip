@@ -571,9 +571,15 @@ static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const voi
     {
         // wgrad8_kernel: 8 waves, double-buffered samples; needs two staging buffers in the LDS and Cb <= 128
         static const char *e8 = std::getenv("CAE_WG8");
-        const int x_instr = (a.HR * a.HC * 4 + 63) / 64, y_instr = (128 * (cb / 8) + 63) / 64;
+        // up to 128 b channels per launch; a wider Y (192) goes in two halves of 96 (three of the four b-tile waves busy)
+        // (measured: the two-launch form is SLOWER than wgrad_kernel<2> on the canonical 192-channel layers -- 13.97 vs 13.59 ms
+        //  per 128 x 256^2 step, X staged twice and a quarter of the waves idle -- so it is opt-in: CAE_WG8_WIDE=1)
+        static const char *ew = std::getenv("CAE_WG8_WIDE");
+        const bool wide_off = cb > 128 && !(ew && ew[0] == '1');
+        const int parts = cb <= 128 ? 1 : 2, cbl = cb / parts;
+        const int x_instr = (a.HR * a.HC * 4 + 63) / 64, y_instr = (128 * (cbl / 8) + 63) / 64;
         const size_t lds8 = 2 * (size_t)(x_instr + y_instr) * 1024;
-        if (!(e8 && e8[0] == '0') && cb <= 128 && x_instr <= 64 && lds8 <= 160 * 1024) {
+        if (!(e8 && e8[0] == '0') && !wide_off && cbl % 32 == 0 && cbl <= 128 && x_instr <= 64 && lds8 <= 160 * 1024) {
             static size_t attr = 0;
             if (lds8 > attr) {
                 HIP_TRY(hipFuncSetAttribute((const void *)wgrad8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
@@ -582,8 +588,15 @@ static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const voi
             const int tpi = a.tiles_x * a.tiles_y;
             // sample lanes: about two rounds of blocks over the 256 CUs, each block walking n, n + step, ...
             const int step = std::max(1, std::min(n, 512 / std::max(1, tpi * a_tiles * tap_groups)));
-            hipLaunchKernelGGL(wgrad8_kernel, dim3(tpi * step, a_tiles, tap_groups), dim3(512), lds8, st, a, tpi, step);
-            HIP_TRY(hipGetLastError());
+            for (int part = 0; part < parts; ++part) {
+                WGArgs b = a;
+                b.Cbs = cb;
+                b.cb0 = part * cbl;
+                b.Cb = cbl;
+                b.m_ypp = (unsigned)(((1ull << 32) + (unsigned)(cbl / 8) - 1) / (unsigned)(cbl / 8));
+                hipLaunchKernelGGL(wgrad8_kernel, dim3(tpi * step, a_tiles, tap_groups), dim3(512), lds8, st, b, tpi, step);
+                HIP_TRY(hipGetLastError());
+            }
             return CAE_OK;
         }
     }

@@ -458,6 +458,7 @@ struct WGArgs {
     int kk;            // taps of the layer
     int dymin, dxmin, HR, HC;
     int tiles_x, tiles_y, total_tiles;
+    int cb0, Cbs;      // wgrad8_kernel: first b channel of this launch and the channel count of Y / gW rows (Cb = this launch's share)
     short dy[MAX_TAPS], dx[MAX_TAPS];
 };
 
@@ -642,9 +643,9 @@ __global__ void __launch_bounds__(512, 1) wgrad8_kernel(const WGArgs p, int tile
         const int pos = (int)__umulhi((unsigned)pc, p.m_ypp), part = pc - pos * ypp;
         const int i_ = i0 + (pos >> 4), jj = j0 + (pos & 15);
         const bool ok = i_ < p.OH && jj < p.OW;  // positions outside contribute zero
-        yoff[i] = ok ? (unsigned)(((i_ * p.OW + jj) * p.Cb) * 2 + part * 16) : 0xFFFFFFFFu;
+        yoff[i] = ok ? (unsigned)(((i_ * p.OW + jj) * p.Cbs + p.cb0) * 2 + part * 16) : 0xFFFFFFFFu;
     }
-    const size_t x_sample = (size_t)p.H * p.W * p.Ca * 2, y_sample = (size_t)p.OH * p.OW * p.Cb * 2;
+    const size_t x_sample = (size_t)p.H * p.W * p.Ca * 2, y_sample = (size_t)p.OH * p.OW * p.Cbs * 2;
     auto issue = [&](int n, char *buf) {
         const char *x_n = (const char *)p.x + (size_t)n * x_sample;
 #pragma unroll
@@ -716,7 +717,7 @@ __global__ void __launch_bounds__(512, 1) wgrad8_kernel(const WGArgs p, int tile
                 static_for<16>([&](auto r_tag) __attribute__((always_inline)) {
                     constexpr int r = decltype(r_tag)::value;
                     const int a = 32 * at + acc_row(r) + 4 * h;
-                    atomicAdd(p.gw + ((size_t)(tap0 + t) * p.Ca + a) * p.Cb + 32 * wb + m, acc[t][r]);
+                    atomicAdd(p.gw + ((size_t)(tap0 + t) * p.Ca + a) * p.Cbs + p.cb0 + 32 * wb + m, acc[t][r]);
                 });
             }
         });
