@@ -56,7 +56,8 @@ int launch_gg8(GGArgs &a, hipStream_t st) {
     }
     // samples per block: enough blocks for two rounds over the 256 CUs, the rest of the batch amortises a block's prologue
     const size_t tiles = (size_t)a.tiles_x * a.tiles_y;
-    static const int forced = std::getenv("CAE_GG8_NPB") ? std::atoi(std::getenv("CAE_GG8_NPB")) : 0;
+    const char *enpb = std::getenv("CAE_GG8_NPB");  // (read per call: tests and A/B runs switch it)
+    const int forced = enpb ? std::atoi(enpb) : 0;
     a.npb = forced > 0 ? std::min(forced, a.N) : (int)std::min<size_t>(std::max<size_t>((size_t)a.N * tiles / 512, 1), (size_t)a.N);
     const unsigned grid = (unsigned)(tiles * (size_t)((a.N + a.npb - 1) / a.npb));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);

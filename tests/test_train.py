@@ -91,6 +91,49 @@ def test_conv_kernels(cae, cin, cout, ks, shape):
     assert rel(gb[:cout], gz.sum(dim=(0, 2, 3))) < 1e-3
 
 
+@pytest.mark.parametrize('npb', ['', '3'])
+def test_conv_kernels_walk_several_samples_per_block(cae, npb, monkeypatch):
+    """gg8_kernel / wgrad8_kernel on the canonical 128 -> 128 layer with blocks that walk several samples (the shapes of the
+    other tests give every block one sample): 8 samples of 72 x 120, forward, both data-gradient forms and the weight gradient;
+    CAE_GG8_NPB=3 forces ragged sample groups (3, 3, 2) in the gather-GEMM, the weight gradient walks 2 samples per block."""
+    from cnn_autoencoder_amd import _lib, train
+    L = _lib.lib()
+    if npb:
+        monkeypatch.setenv('CAE_GG8_NPB', npb)
+    torch.manual_seed(7)
+    n, c, h, w, ks = 8, 128, 72, 120, 3
+    x = bf(torch.randn(n, c, h, w)).requires_grad_(True)
+    wt = bf(torch.randn(c, c, ks, ks) / (c * ks * ks) ** 0.5).requires_grad_(True)
+    z = F.conv2d(F.pad(x, (1, 1, 1, 1), mode='reflect'), wt, None, stride=2)
+    gz = bf(torch.randn_like(z))
+    z.backward(gz)
+    oh, ow = z.shape[2:]
+    x16 = to_t(x.detach(), c, torch.bfloat16)
+    wp = train._pack(wt.detach().cuda(), 1, ks)
+    z32 = torch.empty((n, oh, ow, c), device='cuda')
+    _lib.check(L.cae_t_conv_forward(x16.data_ptr(), n, h, w, c, wp.data_ptr(), ks, z32.data_ptr(), None, c, None, None))
+    assert rel(from_t(z32, c), z.detach()) < 1e-3
+    g16 = to_t(gz, c, torch.bfloat16)
+    wpd = train._pack(wt.detach().cuda(), 0, ks)
+    gext = torch.full((n, h + 2, w + 2, c), float('nan'), device='cuda')
+    _lib.check(L.cae_t_conv_dgrad_ext(g16.data_ptr(), n, oh, ow, c, wpd.data_ptr(), ks, h, w, gext.data_ptr(), c, None))
+    gx16 = torch.empty((n, h, w, c), device='cuda', dtype=torch.bfloat16)
+    _lib.check(L.cae_t_fold_to_bf16(gext.data_ptr(), n, h, w, 1, c, gx16.data_ptr(), None))
+    assert rel(from_t(gx16, c), x.grad) < 1e-2
+    gw = torch.empty((ks * ks, c, c), device='cuda')
+    _lib.check(L.cae_t_wgrad(x16.data_ptr(), n, h, w, c, g16.data_ptr(), oh, ow, c, ks, 1, gw.data_ptr(), None))
+    assert rel(train._weight_grad(gw, (c, c), ks), wt.grad) < 1e-3
+    # the transposed forward of the same weights (four parity launches), as ConvTranspose2d
+    xt = bf(torch.randn(n, c, oh, ow))
+    wtt = bf(torch.randn(c, c, ks, ks) / (c * ks * ks) ** 0.5)
+    u = F.conv_transpose2d(xt, wtt, None, stride=2, padding=1, output_padding=1)
+    u32 = torch.empty((n, 2 * oh, 2 * ow, c), device='cuda')
+    wpt = train._pack(wtt.cuda(), 0, ks)
+    _lib.check(L.cae_t_deconv_forward(to_t(xt, c, torch.bfloat16).data_ptr(), n, oh, ow, c, wpt.data_ptr(), ks, u32.data_ptr(),
+                                      None, c, None, None))
+    assert rel(from_t(u32, c), u) < 1e-3
+
+
 @pytest.mark.parametrize('cin,cout,ks,shape', [(192, 128, 3, (2, 9, 13)), (128, 128, 3, (1, 20, 17)), (128, 3, 3, (2, 24, 24)),
                                                (48, 96, 5, (1, 11, 19)), (32, 32, 5, (2, 16, 16))])
 def test_deconv_kernels(cae, cin, cout, ks, shape):
