@@ -71,14 +71,16 @@ static __global__ void fold_inplace_kernel(float *g, int H, int W, int P, int C)
     };
     if (job < 2 * P) {
         const int y = job < P ? 1 + job : H - 1 - P + (job - P);
-        if (y < 0 || y >= H || !row_folds(y) || (job >= P && y <= P)) return;  // (tiny images: the two bands overlap)
+        // (tiny images: the two bands overlap -- a row of the second band that the first band owns is skipped; row 0 is NOT in
+        //  the first band: `y <= P` here dropped it for H <= P + 1, found by tests/fuzz/fuzz_train.py on 3 x 5 inputs with k = 5)
+        if (y < 0 || y >= H || !row_folds(y) || (job >= P && y >= 1 && y <= P)) return;
         for (int x = wave; x < W; x += nw) fix(y, x);
     } else {
         for (int y = wave; y < H; y += nw) {
             if (row_folds(y)) continue;  // done by its row block
             for (int k = 0; k < 2 * P; ++k) {
                 const int x = k < P ? 1 + k : W - 1 - P + (k - P);
-                if (x < 0 || x >= W || !col_folds(x) || (k >= P && x <= P)) continue;
+                if (x < 0 || x >= W || !col_folds(x) || (k >= P && x >= 1 && x <= P)) continue;
                 fix(y, x);
             }
         }

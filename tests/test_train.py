@@ -169,7 +169,9 @@ def test_deconv_kernels(cae, cin, cout, ks, shape):
 @pytest.mark.parametrize('fused', [False, True])
 @pytest.mark.parametrize('inverse', [False, True])
 @pytest.mark.parametrize('c,shape,pad', [(128, (2, 19, 23), 1), (48, (1, 40, 31), 2), (192, (1, 9, 14), 0), (32, (3, 8, 8), 1),
-                                         (96, (2, 33, 17), 2), (128, (4, 64, 64), 0)])
+                                         (96, (2, 33, 17), 2), (128, (4, 64, 64), 0),
+                                         # tiny images: the two fold bands of fold_inplace_kernel overlap and row / column 0 folds too
+                                         (32, (2, 3, 5), 2), (64, (1, 2, 3), 1), (32, (1, 4, 3), 2)])
 def test_gdn_kernels(cae, inverse, c, shape, pad, fused, monkeypatch):
     """fp32 GDN / IGDN forward and backward (with the reflect fold of an extended-domain gradient) against autograd:
     the three-kernel form and the fused pair (forward saving its factor, one-kernel backward; up to 128 channels)."""
