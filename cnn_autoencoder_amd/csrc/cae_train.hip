@@ -588,7 +588,14 @@ static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const voi
             }
             const int tpi = a.tiles_x * a.tiles_y;
             // sample lanes: about two rounds of blocks over the 256 CUs, each block walking n, n + step, ...
-            const int step = std::max(1, std::min(n, 512 / std::max(1, tpi * a_tiles * tap_groups)));
+            // sample lanes: about ONE block per CU, and at least four samples per block -- every block ends with an atomic flush
+            // of its 9 x 32 x Cb partial sums, and that flush, not the contraction, set the time with more blocks
+            // (128 -> 128, 128^2 / 64^2 inputs; batch 128: 512 blocks 0.50 / 0.18 ms, 256 blocks 0.46 / 0.14 ms;
+            //  batch 16: 512 blocks 0.15 / 0.13 ms, 256 / 128 blocks 0.105 / 0.053 ms).  CAE_WG8_BLOCKS overrides the target.
+            const char *estep = std::getenv("CAE_WG8_BLOCKS");
+            const int target = estep ? std::max(1, std::atoi(estep)) : 256;
+            const int base = std::max(1, tpi * a_tiles * tap_groups);
+            const int step = std::max(1, std::min(std::max(1, estep ? n : n / 4), target / base));
             for (int part = 0; part < parts; ++part) {
                 WGArgs b = a;
                 b.Cbs = cb;
@@ -601,7 +608,8 @@ static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const voi
             return CAE_OK;
         }
     }
-    const int ksplit = std::max(1, std::min(a.total_tiles, 512 / (a_tiles * tap_groups)));
+    const char *eblk = std::getenv("CAE_WG_BLOCKS");  // (A/B)
+    const int ksplit = std::max(1, std::min(a.total_tiles, (eblk ? std::max(1, std::atoi(eblk)) : 512) / (a_tiles * tap_groups)));
     if (cb / 32 <= 4) return launch_wg_t<1>(a, lds, ksplit, a_tiles, tap_groups, st);
     return launch_wg_t<2>(a, lds, ksplit, a_tiles, tap_groups, st);
 }
