@@ -579,7 +579,8 @@ static int wgrad_impl(const void *xbig16, int n, int h, int w, int ca, const voi
         const bool wide_off = cb > 128 && !(ew && ew[0] == '1');
         const int parts = cb <= 128 ? 1 : 2, cbl = cb / parts;
         const int x_instr = (a.HR * a.HC * 4 + 63) / 64, y_instr = (128 * (cbl / 8) + 63) / 64;
-        const size_t lds8 = 2 * (size_t)(x_instr + y_instr) * 1024;
+        // (two staging buffers; at least the 80 KiB in which the position groups merge their partial sums at the end)
+        const size_t lds8 = std::max<size_t>(2 * (size_t)(x_instr + y_instr) * 1024, 4 * 5 * 16 * 64 * sizeof(float));
         if (!(e8 && e8[0] == '0') && !wide_off && cbl % 32 == 0 && cbl <= 128 && x_instr <= 64 && lds8 <= 160 * 1024) {
             static size_t attr = 0;
             if (lds8 > attr) {

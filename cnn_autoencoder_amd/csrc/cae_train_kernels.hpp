@@ -708,9 +708,34 @@ __global__ void __launch_bounds__(512, 1) wgrad8_kernel(const WGArgs p, int tile
         }
     }
 
-    // D: register r = a-channel acc_row(r) + 4h of the a-tile, lane = b-channel
+    // The two position groups add their partial sums in LDS first (the staging buffers are dead now), so that a block flushes
+    // each of its 9 x 32 x Cb sums with ONE atomic instead of two: group 1 parks five, then four taps (20 KiB per wave), group 0
+    // adds them to its own.
     const int h = lane >> 5, m = lane & 31;
-    if (wb < nbt) {
+    {
+        float *park = (float *)smem + (size_t)wb * (5 * 16 * 64) + lane;
+        static_for<2>([&](auto half_tag) __attribute__((always_inline)) {
+            constexpr int half = decltype(half_tag)::value, t0 = half * 5, t1 = half ? 9 : 5;
+            __syncthreads();  // every wave is done with the staging buffers / group 0 has read the previous half
+            if (kg == 1) {
+                static_for<t1 - t0>([&](auto i_tag) __attribute__((always_inline)) {
+                    constexpr int t = t0 + decltype(i_tag)::value;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) park[((t - t0) * 16 + r) * 64] = acc[t][r];
+                });
+            }
+            __syncthreads();
+            if (kg == 0) {
+                static_for<t1 - t0>([&](auto i_tag) __attribute__((always_inline)) {
+                    constexpr int t = t0 + decltype(i_tag)::value;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += park[((t - t0) * 16 + r) * 64];
+                });
+            }
+        });
+    }
+    // D: register r = a-channel acc_row(r) + 4h of the a-tile, lane = b-channel
+    if (kg == 0 && wb < nbt) {
         static_for<9>([&](auto t_tag) __attribute__((always_inline)) {
             constexpr int t = decltype(t_tag)::value;
             if (t < ntaps) {
