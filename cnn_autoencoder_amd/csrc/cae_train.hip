@@ -69,7 +69,32 @@ int launch_gg8(GGArgs &a, hipStream_t st) {
 bool try_gg8(GGArgs &a, int NT, hipStream_t st, int &rc) {
     static const char *e8 = std::getenv("CAE_GG8");
     static const bool off = std::getenv("CAE_GG_LEGACY") != nullptr || (e8 && e8[0] == '0');
-    if (off || a.nq == 0 || (a.nq * a.HR * a.HC + 63) / 64 > 80) return false;
+    if (off) return false;
+    const char *ewide = std::getenv("CAE_GG8_WIDE");  // "0": 192-channel outputs stay on gather_gemm_kernel (A/B)
+    if (NT == 6 && !(ewide && ewide[0] == '0') && (a.ntaps == 9 || a.ntaps == 4 || a.ntaps == 2 || a.ntaps == 1)) {
+        // 192 output channels: two launches of three n-tiles (six do not leave room for two slice buffers in the LDS)
+        int nq = 0;
+        for (int q : {4, 2}) {
+            const size_t slice = (size_t)((q * a.HR * a.HC + 63) / 64) * 1024 + (size_t)a.ntaps * 3 * (q / 2) * 1024;
+            if (2 * slice <= 160 * 1024 && (q * a.HR * a.HC + 63) / 64 <= 80) {
+                nq = q;
+                break;
+            }
+        }
+        if ((a.ntaps == 9 && nq != 2) || (a.ntaps != 9 && nq != 4)) return false;
+        for (int part = 0; part < 2; ++part) {
+            GGArgs b = a;
+            b.nq = nq;
+            b.nt0 = 3 * part;
+            b.nt_all = 6;
+            rc = a.ntaps == 9 ? launch_gg8<3, 2, 9>(b, st)
+                 : a.ntaps == 4 ? launch_gg8<3, 4, 4>(b, st)
+                 : a.ntaps == 2 ? launch_gg8<3, 4, 2>(b, st) : launch_gg8<3, 4, 1>(b, st);
+            if (rc) return true;
+        }
+        return true;
+    }
+    if (a.nq == 0 || (a.nq * a.HR * a.HC + 63) / 64 > 80) return false;
     if (NT == 4 && a.nq == 2 && a.ntaps == 9) { rc = launch_gg8<4, 2, 9>(a, st); return true; }
     if (NT == 4 && a.nq == 4 && a.ntaps == 4) { rc = launch_gg8<4, 4, 4>(a, st); return true; }
     if (NT == 4 && a.nq == 4 && a.ntaps == 2) { rc = launch_gg8<4, 4, 2>(a, st); return true; }

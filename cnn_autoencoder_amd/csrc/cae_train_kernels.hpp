@@ -84,6 +84,8 @@ struct GGArgs {
     unsigned m_plane, m_hc;  // ceil(2^32 / (HR * HC)), ceil(2^32 / HC): exact quotients of piece indices by __umulhi
     int nq;             // pipelined form: 8-channel quarters of the contraction per staged slice (4 = a chunk, 2 = half), else 0
     int npb;            // gg8_kernel: consecutive samples a block walks (same tile of each)
+    int nt0, nt_all;    // gg8_kernel: first n-tile of this launch and the n-tiles of the packed weights / output rows (0: NT):
+                        // a 192-channel output goes as two launches of three n-tiles
     int tiles_x, tiles_y;
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
 };
@@ -341,6 +343,7 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
     }
     // this thread's weight pieces of a slice, relative to the slice's first k-step: [tap][nt][k-step of the slice]
     constexpr int MAXW = (W_INSTR + NW - 1) / NW;
+    const int nta = p.nt_all ? p.nt_all : NT;  // n-tiles of the packed weights (this launch covers NT of them from p.nt0)
     unsigned woff[MAXW];
 #pragma unroll
     for (int i = 0; i < MAXW; ++i) {
@@ -348,9 +351,9 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
         f = f < W_INSTR ? f : W_INSTR - 1;
         const int tl = f / (NT * KSTEPS), rest = f - tl * (NT * KSTEPS);
         const int nt = rest / KSTEPS, ks = rest - nt * KSTEPS;
-        woff[i] = (unsigned)(((p.wt[tl] * (NT * 2) + nt * 2 + ks) * 1024) + lane * 16);
+        woff[i] = (unsigned)(((p.wt[tl] * (nta * 2) + (p.nt0 + nt) * 2 + ks) * 1024) + lane * 16);
     }
-    const unsigned chunk_bytes = (unsigned)p.ktaps * (NT * 2) * 1024;
+    const unsigned chunk_bytes = (unsigned)p.ktaps * (nta * 2) * 1024;
     const int slices = p.Ck / (8 * NQ);
     constexpr int PER_CHUNK = 4 / NQ;
 
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
     auto init_acc = [&]() {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const float b = p.bias ? p.bias[32 * nt + m] : 0.0f;
+            const float b = p.bias ? p.bias[32 * (p.nt0 + nt) + m] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = b;
         }
@@ -423,7 +426,7 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
                 const int li = i0 + 2 * wave + (mp >> 4), lj = j0 + (mp & 15);
                 const int oy = p.SO * li + p.oy0, ox = p.SO * lj + p.ox0;
                 if (li < p.LH && lj < p.LW && oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW && (!(GG8_ABL & 4) || p.N < 0)) {
-                    const size_t base = (((size_t)n * p.OH + oy) * p.OW + ox) * p.Cn + m;
+                    const size_t base = (((size_t)n * p.OH + oy) * p.OW + ox) * p.Cn + 32 * p.nt0 + m;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         float v = acc[nt][r];
