@@ -199,9 +199,88 @@ int strided_corr(const void *in16, int n, int ih, int iw, int ck, const void *pa
 //   shift = P : cropped domain   out[Y] = sum in[(Y + P - ky) / 2]  (ConvTranspose2d(k, 2, k//2, output_padding 1))
 //   shift = 0 : extended domain  out[Y] = sum in[(Y - ky) / 2],  Y in [0, 2 ih + k - 2]   (data gradient of a valid
 //               convolution on the reflect-padded input; Y = y + P)
+// all four output parities of the k = 3 transpose in one launch (gg8t_kernel); -> false when the shape is not covered
+template <bool EXT>
+int launch_gg8t(GGArgs &a, hipStream_t st) {
+    auto kern = gg8t_kernel<EXT>;
+    const size_t h_instr = (size_t)(4 * a.HR * a.HC + 63) / 64;
+    const size_t lds = 2 * (h_instr + 9 * 2 * 2) * 1024;
+    static size_t attr = 0;
+    if (lds > attr) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    const size_t tiles = (size_t)a.tiles_x * a.tiles_y, halves = (size_t)a.Cn / 64;
+    a.npb = (int)std::min<size_t>(std::max<size_t>((size_t)a.N * tiles * halves / 512, 1), (size_t)a.N);
+    const unsigned grid = (unsigned)(tiles * (size_t)((a.N + a.npb - 1) / a.npb));
+    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)halves), dim3(512), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return CAE_OK;
+}
+
+bool try_gg8t(const void *in16, int n, int ih, int iw, int ck, const void *packed, int shift, float *out32, void *out16, int cn,
+              int oh, int ow, const float *bias, hipStream_t st, int act, int &rc) {
+    const char *e = std::getenv("CAE_GG8T");
+    if ((e && e[0] == '0') || std::getenv("CAE_GG_LEGACY") || cn % 64 || bad_channels(ck) || bad_channels(cn)) return false;
+    GGArgs a{};
+    a.in = in16;
+    a.out32 = out32;
+    a.out16 = out16;
+    a.wp = packed;
+    a.bias = bias;
+    a.N = n;
+    a.IH = ih;
+    a.IW = iw;
+    a.Ck = ck;
+    a.Cn = cn;
+    a.OH = oh;
+    a.OW = ow;
+    a.LH = (oh + 1) / 2;
+    a.LW = (ow + 1) / 2;
+    a.S = 1;
+    a.SO = 2;
+    a.act = act;
+    a.ktaps = 9;
+    a.ntaps = 9;
+    int nt = 0, dymin = 1 << 20, dymax = -(1 << 20), dxmin = 1 << 20, dxmax = -(1 << 20);
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px)  // parity-major: (0,0), (0,1), (1,0), (1,1) = gg8t_parity's order
+            for (int ky = 0; ky < 3; ++ky) {
+                if (((py + shift - ky) & 1) != 0) continue;
+                for (int kx = 0; kx < 3; ++kx) {
+                    if (((px + shift - kx) & 1) != 0) continue;
+                    a.dy[nt] = (short)((py + shift - ky) / 2);
+                    a.dx[nt] = (short)((px + shift - kx) / 2);
+                    a.wt[nt] = (short)(ky * 3 + kx);
+                    dymin = std::min<int>(dymin, a.dy[nt]);
+                    dymax = std::max<int>(dymax, a.dy[nt]);
+                    dxmin = std::min<int>(dxmin, a.dx[nt]);
+                    dxmax = std::max<int>(dxmax, a.dx[nt]);
+                    ++nt;
+                }
+            }
+    if (nt != 9) return false;
+    a.dymin = dymin;
+    a.dxmin = dxmin;
+    a.HR = 15 + (dymax - dymin) + 1;
+    a.HC = 15 + (dxmax - dxmin) + 1;
+    if ((4 * a.HR * a.HC + 63) / 64 > 32) return false;
+    a.m_hc = (unsigned)(((1ull << 32) + (unsigned)a.HC - 1) / (unsigned)a.HC);
+    a.tiles_x = (a.LW + 15) / 16;
+    a.tiles_y = (a.LH + 15) / 16;
+    a.zero = zero_page();
+    if (!a.zero) return false;
+    rc = shift == 0 ? launch_gg8t<true>(a, st) : launch_gg8t<false>(a, st);
+    return true;
+}
+
 int strided_corr_t(const void *in16, int n, int ih, int iw, int ck, const void *packed, int ks, int shift, float *out32,
                    void *out16, int cn, int oh, int ow, const float *bias, hipStream_t st, int act = 0) {
     if (ks != 3 && ks != 5) return fail(CAE_ERR_UNSUPPORTED, "kernel_size %d not supported (3 or 5)", ks);
+    int rc8t = CAE_OK;
+    if (ks == 3 && (shift == 0 || shift == 1) &&
+        try_gg8t(in16, n, ih, iw, ck, packed, shift, out32, out16, cn, oh, ow, bias, st, act, rc8t))
+        return rc8t;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             GGArgs a{};

@@ -444,6 +444,151 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// gg8t: the TRANSPOSE of the strided correlation (k = 3) with its four output parities in ONE launch.
+//   As four gg8 launches (1 + 2 + 2 + 4 taps) the transposed convolutions ran at half the rate of the strided ones for the same
+//   FLOP: every launch stages the same input halo again and its blocks live for one to four taps only.  Here a block = 16 x 16
+//   logical positions (i, j) x 64 output channels (two n-tiles; blockIdx.y picks them) and produces all four output pixels
+//   (2i + py, 2j + px) of every position: 9 taps per 32-channel slice, 4 x 2 accumulator tiles per wave (128 registers), one
+//   17 x 17 halo.  The taps come parity-major from the host (counts {1, 2, 2, 4} for the cropped form = ConvTranspose2d forward,
+//   {4, 2, 2, 1} for the extended form = data gradient of the strided convolution), so tap -> parity is static.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool EXT>
+__host__ __device__ constexpr int gg8t_parity(int t) {
+    return EXT ? (t < 4 ? 0 : (t < 6 ? 1 : (t < 8 ? 2 : 3))) : (t < 1 ? 0 : (t < 3 ? 1 : (t < 5 ? 2 : 3)));
+}
+
+template <bool EXT>
+__global__ void __launch_bounds__(512, 1) gg8t_kernel(const GGArgs p) {
+    constexpr int NW = 8, NT = 2, NQ = 4, KSTEPS = 2, NTAPS = 9;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n0 = (bid / p.tiles_y) * p.npb;
+    const int nsamp = min(p.npb, p.N - n0);
+    const int i0 = ty * 16, j0 = tx * 16;
+    const int nt0 = NT * blockIdx.y, nta = p.Cn / 32;
+
+    const int plane = p.HR * p.HC;
+    const int hpieces = NQ * plane, h_instr = (hpieces + 63) / 64;
+    constexpr int W_INSTR = NTAPS * NT * KSTEPS;
+    const size_t buf_bytes = (size_t)(h_instr + W_INSTR) * 1024;
+    const size_t sample_bytes = (size_t)p.IH * p.IW * p.Ck * 2;
+
+    constexpr int MAXP = 4;  // 4 x 18 x 18 pieces / 64 / 8 waves
+    unsigned hoff[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        int pc = (wave + i * NW) * 64 + lane;
+        pc = pc < hpieces ? pc : hpieces - 1;
+        const int quarter = pc % NQ, rem = pc / NQ;  // pixel-major (see gg8_kernel)
+        const int r = (int)__umulhi((unsigned)rem, p.m_hc), c = rem - r * p.HC;
+        const int iy = i0 + p.dymin + r, ix = j0 + p.dxmin + c;
+        const bool ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        hoff[i] = ok ? (unsigned)((iy * p.IW + ix) * p.Ck * 2 + quarter * 16) : 0xFFFFFFFFu;
+    }
+    constexpr int MAXW = (W_INSTR + NW - 1) / NW;
+    unsigned woff[MAXW];
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) {
+        int f = wave + NW * i;
+        f = f < W_INSTR ? f : W_INSTR - 1;
+        const int tl = f / (NT * KSTEPS), rest = f - tl * (NT * KSTEPS);
+        const int nt = rest / KSTEPS, ks = rest - nt * KSTEPS;
+        woff[i] = (unsigned)(((p.wt[tl] * (nta * 2) + (nt0 + nt) * 2 + ks) * 1024) + lane * 16);
+    }
+    const unsigned chunk_bytes = (unsigned)p.ktaps * (nta * 2) * 1024;
+    const int slices = p.Ck / 32;
+
+    auto issue = [&](int ns, int sl, char *buf) {
+        const char *in_s = (const char *)p.in + (size_t)(n0 + ns) * sample_bytes + sl * 64;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int j = wave + i * NW;
+            if (j < h_instr) glds16(hoff[i] != 0xFFFFFFFFu ? (const void *)(in_s + hoff[i]) : p.zero, buf + j * 1024);
+        }
+        char *wb = buf + (size_t)h_instr * 1024;
+        const char *wsrc = (const char *)p.wp + (size_t)sl * chunk_bytes;
+#pragma unroll
+        for (int i = 0; i < MAXW; ++i) {
+            const int f = wave + NW * i;
+            if (f < W_INSTR) glds16(wsrc + woff[i], wb + f * 1024);
+        }
+    };
+
+    f32x16 acc[4][NT];
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float b = p.bias ? p.bias[32 * (nt0 + nt) + m] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][nt][r] = b;
+        }
+    };
+    init_acc();
+
+    const int a_base = (((2 * wave + (m >> 4)) * p.HC + (m & 15)) * NQ + h) * 16;
+    const int total = nsamp * slices;
+    issue(0, 0, smem);
+    int ns = 0, sl = 0;
+    for (int it = 0; it < total; ++it) {
+        char *cur = smem + (size_t)(it & 1) * buf_bytes;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (it + 1 < total) {
+            const bool wrap = sl + 1 == slices;
+            issue(wrap ? ns + 1 : ns, wrap ? 0 : sl + 1, smem + (size_t)((it + 1) & 1) * buf_bytes);
+        }
+        const char *ab = cur + a_base;
+        const char *wb = cur + (size_t)h_instr * 1024 + lane * 16;
+        static_for<NTAPS>([&](auto t_tag) __attribute__((always_inline)) {
+            constexpr int t = decltype(t_tag)::value;
+            constexpr int par = gg8t_parity<EXT>(t);
+            const int toff = ((p.dy[t] - p.dymin) * p.HC + (p.dx[t] - p.dxmin)) * (NQ * 16);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const bf16x8 a = *(const bf16x8 *)(ab + toff + ks * 32);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 b = *(const bf16x8 *)(wb + ((t * NT + nt) * KSTEPS + ks) * 1024);
+                    acc[par][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[par][nt], 0, 0, 0);
+                }
+            }
+        });
+        if (++sl == slices) {
+            const int n = n0 + ns;
+            static_for<4>([&](auto q_tag) __attribute__((always_inline)) {
+                constexpr int par = decltype(q_tag)::value, py = par >> 1, px = par & 1;
+                static_for<16>([&](auto r_tag) __attribute__((always_inline)) {
+                    constexpr int r = decltype(r_tag)::value;
+                    const int mp = acc_row(r) + 4 * h;
+                    const int li = i0 + 2 * wave + (mp >> 4), lj = j0 + (mp & 15);
+                    const int oy = 2 * li + py, ox = 2 * lj + px;
+                    if (oy < p.OH && ox < p.OW) {
+                        const size_t base = (((size_t)n * p.OH + oy) * p.OW + ox) * p.Cn + 32 * nt0 + m;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            float v = acc[par][nt][r];
+                            if (p.act) v = v > 0.0f ? v : (p.act == 1 ? 0.01f * v : 0.0f);
+                            if (p.out32) p.out32[base + 32 * nt] = v;
+                            if (p.out16) ((__bf16 *)p.out16)[base + 32 * nt] = (__bf16)v;
+                        }
+                    }
+                });
+            });
+            init_acc();
+            sl = 0;
+            ++ns;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // wgrad:  gW[tap][a][b] += sum over positions (n, i, j) of X[n][2i + dy][2j + dx][a] * Y[n][i][j][b]
 //   block = 4 waves; one 32-channel a-tile, <= 9 taps, every b-tile (wave w: b-tiles w, w + 4, ...);
 //   walks position tiles of 8 x 16 (K = 128), X halo and Y tile pixel-major in LDS, operands by ds_read_b64_tr_b16;
