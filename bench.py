@@ -317,20 +317,25 @@ def train_run(cae, cfg, state, batch, patch, steps, warmup):
     for _ in range(warmup):
         train.train_step(x, model, criterion, opts)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
-        ld = train.train_step(x, model, criterion, opts)
-    e1.record()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    # two timed repetitions of `steps` iterations, the faster one reported (both listed): one repetition of the batch-256 run was
+    # once 3.3 x slower on the device clock itself (82 vs 25 ms per step, not reproducible in five later runs)
+    reps = []
+    for _ in range(2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            ld = train.train_step(x, model, criterion, opts)
+        e1.record()
+        torch.cuda.synchronize()
+        reps.append(((time.perf_counter() - t0) / steps, e0.elapsed_time(e1) / steps))
+    dt, dev_ms = min(reps)
     conv, gdn = train_flops(cfg, patch)
     ideal = batch * (conv / (F16_MFMA_PEAK_TFLOPS * 1e12) + gdn / (FP32_MFMA_PEAK_TFLOPS * 1e12))
     del model, opts
     torch.cuda.empty_cache()
     return dict(batch=batch, patch=patch, steps=steps, ms_per_step=1e3 * dt, samples_per_s=batch / dt,
-                device_ms_per_step=e0.elapsed_time(e1) / steps,
+                device_ms_per_step=dev_ms, ms_per_step_of_each_repetition=[1e3 * r[0] for r in reps],
                 conv_gflop_per_step=batch * conv / 1e9, gdn_gflop_per_step=batch * gdn / 1e9,
                 mixed_roofline_ms=1e3 * ideal, frac=ideal / dt, loss=float(ld['loss']))
 
