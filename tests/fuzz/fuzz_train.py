@@ -88,6 +88,15 @@ for case in range(n_cases):
         if e_out > max(3e-3, 2.0 * s_out):
             problems.append(f'{name} output {e_out:.2e} (rounding sensitivity {s_out:.2e})')
         sens = {n_: rel(l.grad, l32.grad) for (n_, l), (_, l32) in zip(pairs, pairs32)}
+        # ... and how far an input perturbation of the size of one bf16 rounding (2^-9 relative) moves them: a gradient that is a
+        # small difference of large sums (the batch-norm bias of a 1 -> 1 stage: 17 % under such a perturbation while the
+        # bf16-vs-fp32 gap of the same restatement showed 0.2 %) is recognised only this way
+        for _ in range(2):
+            units_p, pairs_p = residual_oracle_units(track, act_name)
+            xp = (inp * (1 + 2.0 ** -9 * torch.randn_like(inp))).requires_grad_(True)
+            T.residual_track(xp, units_p, synthesis, bf16=True).backward(g)
+            for (n_, l), (_, lp) in zip(pairs, pairs_p):
+                sens[n_] = max(sens[n_], rel(lp.grad, l.grad))
         got = {k: p.grad.detach().cpu() for k, p in mod.named_parameters() if p.grad is not None}
         prefix = 'synthesis_track.' if synthesis else 'analysis_track.'
         if len(got) != len(pairs):
