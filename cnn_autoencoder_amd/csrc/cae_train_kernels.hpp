@@ -298,6 +298,12 @@ __global__ void __launch_bounds__(256, 1) gather_gemm_kernel(const GGArgs p) {
 //   offsets depend on (ty, tx) only -- as one continuous slice pipeline: sample n + 1's first slice is in flight while
 //   sample n's last slice multiplies and its tile is stored.
 // ---------------------------------------------------------------------------------------------------------------
+// LDS slot of halo piece p (16 bytes): the A-operand reads of a wave step by 2 or 4 pieces from lane to lane (64 bytes: a pixel
+// stride of S * NQ pieces), i.e. they touch 4 of the 16 bank groups -- the PMC pass showed 2.7 - 4.1 conflict cycles per 7 - 8
+// LDS-active cycles in gg8 / gg8t.  XOR-ing bits 4..5 of the piece index into bits 0..1 spreads each run of 16 lanes over all 16
+// groups; the LDS-DMA writes lane-linear slots, so the same involution picks the SOURCE piece of every slot when staging.
+__device__ __forceinline__ int gg8_swz(int piece) { return piece ^ ((piece >> 4) & 3); }
+
 template <int NT, int NQ, int NTAPS>
 __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
     constexpr int NW = 8, KSTEPS = NQ / 2;
@@ -324,7 +330,7 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
     unsigned hoff[MAXP];
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-        int pc = (wave + i * NW) * 64 + lane;
+        int pc = gg8_swz((wave + i * NW) * 64 + lane);  // (the piece that lives in this lane's slot)
         pc = pc < hpieces ? pc : hpieces - 1;
         // pixel-major: the NQ 16-byte quarters of a pixel's slice sit on consecutive lanes = one 32- or 64-byte run of its
         // channel vector (quarter-major, one lane per cache line and every line fetched NQ times, held the kernel at the
@@ -386,8 +392,8 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
     init_acc();
 
     // A operand: halo [row][col][quarter]; position (2 wave + (m >> 4), m & 15), quarter 2 ks + h, tap offset per tap (uniform)
-    const int a_base = (((p.S * (2 * wave + (m >> 4))) * p.HC + p.S * (m & 15)) * NQ + h) * 16;
-    constexpr int a_kstep = 2 * 16;
+    const int a_base = ((p.S * (2 * wave + (m >> 4))) * p.HC + p.S * (m & 15)) * NQ + h;  // (in pieces)
+    constexpr int a_kstep = 2;
 
     const int total = nsamp * slices;
     issue(0, 0, smem);
@@ -399,14 +405,13 @@ __global__ void __launch_bounds__(512, 1) gg8_kernel(const GGArgs p) {
             const bool wrap = sl + 1 == slices;
             issue(wrap ? ns + 1 : ns, wrap ? 0 : sl + 1, smem + (size_t)((it + 1) & 1) * buf_bytes);
         }
-        const char *ab = cur + a_base;
         const char *wb = cur + (size_t)h_instr * 1024 + lane * 16;
         static_for<NTAPS>([&](auto t_tag) __attribute__((always_inline)) {
             constexpr int t = decltype(t_tag)::value;
-            const int toff = ((p.dy[t] - p.dymin) * p.HC + (p.dx[t] - p.dxmin)) * (NQ * 16);  // (uniform; kernel-argument loads, hoisted)
+            const int toff = ((p.dy[t] - p.dymin) * p.HC + (p.dx[t] - p.dxmin)) * NQ;  // (uniform; kernel-argument loads, hoisted)
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-                const bf16x8 a = *(const bf16x8 *)(ab + toff + ks * a_kstep);
+                const bf16x8 a = *(const bf16x8 *)(cur + gg8_swz(a_base + toff + ks * a_kstep) * 16);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const bf16x8 b = *(const bf16x8 *)(wb + ((t * NT + nt) * KSTEPS + ks) * 1024);
@@ -483,9 +488,9 @@ __global__ void __launch_bounds__(512, 1) gg8t_kernel(const GGArgs p) {
     unsigned hoff[MAXP];
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-        int pc = (wave + i * NW) * 64 + lane;
+        int pc = gg8_swz((wave + i * NW) * 64 + lane);
         pc = pc < hpieces ? pc : hpieces - 1;
-        const int quarter = pc % NQ, rem = pc / NQ;  // pixel-major (see gg8_kernel)
+        const int quarter = pc % NQ, rem = pc / NQ;  // pixel-major, swizzled slots (see gg8_kernel)
         const int r = (int)__umulhi((unsigned)rem, p.m_hc), c = rem - r * p.HC;
         const int iy = i0 + p.dymin + r, ix = j0 + p.dxmin + c;
         const bool ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
@@ -533,7 +538,7 @@ __global__ void __launch_bounds__(512, 1) gg8t_kernel(const GGArgs p) {
     };
     init_acc();
 
-    const int a_base = (((2 * wave + (m >> 4)) * p.HC + (m & 15)) * NQ + h) * 16;
+    const int a_base = ((2 * wave + (m >> 4)) * p.HC + (m & 15)) * NQ + h;  // (in pieces)
     const int total = nsamp * slices;
     issue(0, 0, smem);
     int ns = 0, sl = 0;
@@ -544,15 +549,14 @@ __global__ void __launch_bounds__(512, 1) gg8t_kernel(const GGArgs p) {
             const bool wrap = sl + 1 == slices;
             issue(wrap ? ns + 1 : ns, wrap ? 0 : sl + 1, smem + (size_t)((it + 1) & 1) * buf_bytes);
         }
-        const char *ab = cur + a_base;
         const char *wb = cur + (size_t)h_instr * 1024 + lane * 16;
         static_for<NTAPS>([&](auto t_tag) __attribute__((always_inline)) {
             constexpr int t = decltype(t_tag)::value;
             constexpr int par = gg8t_parity<EXT>(t);
-            const int toff = ((p.dy[t] - p.dymin) * p.HC + (p.dx[t] - p.dxmin)) * (NQ * 16);
+            const int toff = ((p.dy[t] - p.dymin) * p.HC + (p.dx[t] - p.dxmin)) * NQ;
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-                const bf16x8 a = *(const bf16x8 *)(ab + toff + ks * 32);
+                const bf16x8 a = *(const bf16x8 *)(cur + gg8_swz(a_base + toff + ks * 2) * 16);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const bf16x8 b = *(const bf16x8 *)(wb + ((t * NT + nt) * KSTEPS + ks) * 1024);
